@@ -1,0 +1,400 @@
+// hvlc_api.hip -- host side of libhvlc.so: the C ABI declared in include/hvlc.h.
+//
+// Mirrors the call sites of the reference's GPU path in runVLCTest
+// (main_test_cu.cu:130-168): where the reference launches
+// vlc_encode_kernel_sm64huff, then preallocBlockSums/prescanArray/deallocBlockSums,
+// then cudaMemset + pack2 on the default stream, hvlc_encode launches k_prepare
+// (table packing + granule reset) and the fused persistent k_encode on the
+// caller's stream.  Nothing here allocates, frees or synchronises inside the
+// launch path once the workspace is large enough (graph-capture friendly), and
+// nothing falls back to a CPU implementation: without a GPU every compute entry
+// point fails with HVLC_ERR_NO_DEVICE / HVLC_ERR_HIP.
+#include "../../include/hvlc.h"
+#include "hvlc_device.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+using namespace hvlc;
+
+struct hvlc_ctx {
+    int       device        = 0;
+    int       cus           = 0;
+    int       blocks_per_cu = 0;
+    int       last_hip      = 0;
+    int       last_grid     = 0;
+    uint8_t*  ws            = nullptr;   // [lut 2 KiB][status/result 64 B][granules...]
+    uint64_t  granule_bytes = 0;         // capacity of the granule region
+    uint64_t  timeout_ticks = 200000000ull;   // 2 s of the 100 MHz real-time counter
+    // pinned host mirror for hvlc_finish
+    uint32_t* h_status      = nullptr;   // [0] flags, [2..3] total bits
+};
+
+namespace {
+
+constexpr uint64_t kLutBytes    = 2048;
+constexpr uint64_t kStatusBytes = 64;
+constexpr uint64_t kHeaderBytes = kLutBytes + kStatusBytes;
+
+#define HVLC_HIP(ctx, call)                                   \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) {                               \
+            if (ctx) (ctx)->last_hip = (int)e_;               \
+            return e_ == hipErrorOutOfMemory ? HVLC_ERR_NOMEM : HVLC_ERR_HIP; \
+        }                                                     \
+    } while (0)
+
+inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
+
+// granule layout for `tiles` tiles: tile_bits | tile_tail | group_desc, each padded to 16 B
+struct Layout { uint64_t tiles_pad, groups_pad, bytes; };
+inline Layout layout_for(uint64_t tiles)
+{
+    Layout l;
+    l.tiles_pad  = round_up(tiles ? tiles : 1, 2);
+    l.groups_pad = round_up((tiles + kGroupTiles - 1) / kGroupTiles + 1, 2);
+    l.bytes      = (2 * l.tiles_pad + l.groups_pad) * 8;
+    return l;
+}
+
+int ensure_workspace(hvlc_ctx* c, uint64_t tiles)
+{
+    const Layout l = layout_for(tiles);
+    if (c->ws && l.bytes <= c->granule_bytes) return HVLC_OK;
+    // growing is not capture-safe; size the context for the largest input up front to avoid it
+    if (c->ws) { HVLC_HIP(c, hipDeviceSynchronize()); HVLC_HIP(c, hipFree(c->ws)); c->ws = nullptr; }
+    const uint64_t want = round_up(l.bytes, 4096);
+    HVLC_HIP(c, hipMalloc((void**)&c->ws, kHeaderBytes + want));
+    c->granule_bytes = want;
+    return HVLC_OK;
+}
+
+inline uint2*    ws_lut(hvlc_ctx* c)    { return (uint2*)c->ws; }
+inline uint32_t* ws_status(hvlc_ctx* c) { return (uint32_t*)(c->ws + kLutBytes); }
+inline uint64_t* ws_result(hvlc_ctx* c) { return (uint64_t*)(c->ws + kLutBytes + 8); }
+inline uint8_t*  ws_gran(hvlc_ctx* c)   { return c->ws + kHeaderBytes; }
+
+void fill_granule_ptrs(hvlc_ctx* c, uint64_t tiles, EncodeParams& p)
+{
+    const Layout l = layout_for(tiles);
+    uint64_t* g = (uint64_t*)ws_gran(c);
+    p.tile_bits  = g;
+    p.tile_tail  = g + l.tiles_pad;
+    p.group_desc = g + 2 * l.tiles_pad;
+    p.status     = ws_status(c);
+    p.result     = ws_result(c);
+    p.timeout_ticks = c->timeout_ticks;
+}
+
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// Persistent grid: every workgroup must be resident at once (see hvlc_device.hip.h).  The
+// occupancy API can over-report by one block per CU for SGPR-heavy 256-thread kernels on
+// ROCm 7.2 (CDNA4 guide), so one block per CU is given back as margin.
+template <typename K>
+int pick_blocks_per_cu(hvlc_ctx* c, K kernel, int cap)
+{
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kThreads, 0) != hipSuccess || occ < 1) occ = 2;
+    int b = occ > 1 ? occ - 1 : 1;
+    if (b > cap) b = cap;
+    const int forced = env_int("HVLC_BLOCKS_PER_CU", 0);
+    if (forced > 0) b = forced < occ ? forced : (occ > 1 ? occ - 1 : 1);
+    (void)c;
+    return b;
+}
+
+std::mutex g_default_mu;
+hvlc_ctx*  g_default_ctx = nullptr;
+
+}  // namespace
+
+extern "C" {
+
+const char* hvlc_version(void) { return "hvlc 0.1 (gfx950)"; }
+
+const char* hvlc_status_string(int s)
+{
+    switch (s) {
+        case HVLC_OK:            return "ok";
+        case HVLC_ERR_ARG:       return "bad argument";
+        case HVLC_ERR_HIP:       return "HIP runtime error";
+        case HVLC_ERR_NOMEM:     return "out of device memory";
+        case HVLC_ERR_TABLE:     return "invalid code table (length > 31 or codeword >= 2^length)";
+        case HVLC_ERR_CAPACITY:  return "output buffer too small";
+        case HVLC_ERR_TIMEOUT:   return "inter-workgroup wait timed out";
+        case HVLC_ERR_NO_DEVICE: return "no HIP device";
+        default:                 return "unknown";
+    }
+}
+
+uint64_t hvlc_out_capacity_words(uint64_t num_words, uint32_t max_len)
+{
+    if (max_len > HVLC_MAX_CODE_LEN) max_len = HVLC_MAX_CODE_LEN;
+    const uint64_t bits = num_words * 4u * (uint64_t)max_len;
+    return bits / 32u + 1u;
+}
+
+uint64_t hvlc_num_segments(uint64_t num_words)
+{
+    return (num_words + HVLC_SEGMENT_WORDS - 1) / HVLC_SEGMENT_WORDS;
+}
+
+int hvlc_create(hvlc_ctx** out, int device, uint64_t max_words)
+{
+    if (!out) return HVLC_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HVLC_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return HVLC_ERR_ARG;
+    hvlc_ctx* c = new (std::nothrow) hvlc_ctx();
+    if (!c) return HVLC_ERR_NOMEM;
+    c->device = device;
+    hipError_t e = hipSetDevice(device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { delete c; return HVLC_ERR_HIP; }
+    c->cus = prop.multiProcessorCount;
+    c->blocks_per_cu = pick_blocks_per_cu(c, k_encode, env_int("HVLC_MAX_BLOCKS_PER_CU", 8));
+    const int to_ms = env_int("HVLC_TIMEOUT_MS", 2000);
+    c->timeout_ticks = (uint64_t)(to_ms > 0 ? to_ms : 2000) * 100000ull;
+    int rc = ensure_workspace(c, (max_words + kTileWords - 1) / kTileWords);
+    if (rc == HVLC_OK && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocDefault) != hipSuccess) rc = HVLC_ERR_NOMEM;
+    if (rc != HVLC_OK) { if (c->ws) (void)hipFree(c->ws); delete c; return rc; }
+    *out = c;
+    return HVLC_OK;
+}
+
+int hvlc_destroy(hvlc_ctx* c)
+{
+    if (!c) return HVLC_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    delete c;
+    return HVLC_OK;
+}
+
+int hvlc_get_launch_info(hvlc_ctx* c, int* grid_blocks, int* blocks_per_cu, int* compute_units)
+{
+    if (!c) return HVLC_ERR_ARG;
+    if (grid_blocks)   *grid_blocks   = c->last_grid;
+    if (blocks_per_cu) *blocks_per_cu = c->blocks_per_cu;
+    if (compute_units) *compute_units = c->cus;
+    return HVLC_OK;
+}
+
+int hvlc_last_hip_error(hvlc_ctx* c) { return c ? c->last_hip : 0; }
+
+int hvlc_encode(hvlc_ctx* c,
+                const uint32_t* d_in, uint64_t num_words,
+                const uint32_t* d_codewords, const uint32_t* d_codewordlens,
+                uint32_t* d_out_bits, uint64_t out_capacity_words,
+                uint64_t* d_out_offsets, uint64_t* d_total_bits,
+                void* stream)
+{
+    if (!c || !d_codewords || !d_codewordlens || !d_out_bits) return HVLC_ERR_ARG;
+    if (num_words && !d_in) return HVLC_ERR_ARG;
+    if (((uintptr_t)d_in & 15u) || ((uintptr_t)d_out_bits & 3u) || ((uintptr_t)d_out_offsets & 7u) ||
+        ((uintptr_t)d_total_bits & 7u))
+        return HVLC_ERR_ARG;
+    if (out_capacity_words < 1) return HVLC_ERR_ARG;
+    HVLC_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+
+    const uint64_t tiles = (num_words + kTileWords - 1) / kTileWords;
+    int rc = ensure_workspace(c, tiles);
+    if (rc != HVLC_OK) return rc;
+
+    EncodeParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = (const uint4*)d_in;  p.num_words = num_words;  p.num_tiles = tiles;
+    p.num_segs = hvlc_num_segments(num_words);
+    p.lut = ws_lut(c);  p.out = d_out_bits;  p.out_cap = out_capacity_words;
+    p.offsets = d_out_offsets;  p.total_bits = d_total_bits;
+    fill_granule_ptrs(c, tiles, p);
+
+    const Layout l = layout_for(tiles);
+    const uint64_t vecs = l.bytes / 16;
+    int pgrid = (int)((vecs + kThreads - 1) / kThreads);
+    if (pgrid < 1) pgrid = 1;
+    if (pgrid > 2048) pgrid = 2048;
+    hipLaunchKernelGGL(k_prepare, dim3(pgrid), dim3(kThreads), 0, s,
+                       d_codewords, d_codewordlens, ws_lut(c), ws_status(c), ws_result(c),
+                       (uint4*)ws_gran(c), vecs, d_out_bits, out_capacity_words, d_total_bits,
+                       tiles == 0 ? 1 : 0);
+    HVLC_HIP(c, hipGetLastError());
+    if (tiles == 0) { c->last_grid = 0; return HVLC_OK; }
+
+    uint64_t grid = (uint64_t)c->cus * (uint64_t)c->blocks_per_cu;
+    if (grid > tiles) grid = tiles;
+    c->last_grid = (int)grid;
+    hipLaunchKernelGGL(k_encode, dim3((unsigned)grid), dim3(kThreads), 0, s, p);
+    HVLC_HIP(c, hipGetLastError());
+    return HVLC_OK;
+}
+
+int hvlc_finish(hvlc_ctx* c, void* stream, uint64_t* total_bits)
+{
+    if (!c) return HVLC_ERR_ARG;
+    HVLC_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    HVLC_HIP(c, hipMemcpyAsync(c->h_status, ws_status(c), 16, hipMemcpyDeviceToHost, s));
+    HVLC_HIP(c, hipStreamSynchronize(s));
+    const uint32_t flags = c->h_status[0];
+    uint64_t bits;
+    memcpy(&bits, &c->h_status[2], 8);
+    if (total_bits) *total_bits = bits;
+    if (flags & kFlagTimeout)  return HVLC_ERR_TIMEOUT;
+    if (flags & kFlagTable)    return HVLC_ERR_TABLE;
+    if (flags & kFlagCapacity) return HVLC_ERR_CAPACITY;
+    return HVLC_OK;
+}
+
+int gpu_vlc_encode(unsigned int* indata, unsigned int num_elements,
+                   unsigned int* outdata, unsigned int* outsize,
+                   unsigned int* codewords, unsigned int* codewordlens)
+{
+    if (!outdata || !outsize || !codewords || !codewordlens || (num_elements && !indata)) return HVLC_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_default_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return HVLC_ERR_NO_DEVICE;
+    if (!g_default_ctx || g_default_ctx->device != dev) {
+        if (g_default_ctx) hvlc_destroy(g_default_ctx);
+        g_default_ctx = nullptr;
+        int rc = hvlc_create(&g_default_ctx, dev, num_elements);
+        if (rc != HVLC_OK) return rc;
+    }
+    hvlc_ctx* c = g_default_ctx;
+    uint32_t maxlen = 0;
+    for (int i = 0; i < 256; ++i) if (codewordlens[i] > maxlen) maxlen = codewordlens[i];
+    if (maxlen > HVLC_MAX_CODE_LEN) return HVLC_ERR_TABLE;
+    const uint64_t cap = hvlc_out_capacity_words(num_elements, maxlen);
+    uint32_t *d_in = nullptr, *d_tab = nullptr, *d_out = nullptr;
+    int rc = HVLC_OK;
+    hipError_t e = hipMalloc((void**)&d_in, (size_t)(num_elements ? num_elements : 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_tab, 2048);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, (size_t)cap * 4);
+    if (e == hipSuccess && num_elements) e = hipMemcpy(d_in, indata, (size_t)num_elements * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_tab, codewords, 1024, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_tab + 256, codewordlens, 1024, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { c->last_hip = (int)e; rc = e == hipErrorOutOfMemory ? HVLC_ERR_NOMEM : HVLC_ERR_HIP; }
+    uint64_t bits = 0;
+    if (rc == HVLC_OK) rc = hvlc_encode(c, d_in, num_elements, d_tab, d_tab + 256, d_out, cap, nullptr, nullptr, nullptr);
+    if (rc == HVLC_OK) rc = hvlc_finish(c, nullptr, &bits);
+    if (rc == HVLC_OK) {
+        e = hipMemcpy(outdata, d_out, (size_t)(bits / 32 + 1) * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { c->last_hip = (int)e; rc = HVLC_ERR_HIP; }
+        *outsize = (unsigned int)((bits >> 5) * 4u + (((unsigned int)bits & 31u) + 7u) / 8u);   // cpuencode.cpp:44-45
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_tab) (void)hipFree(d_tab);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+int hvlc_segment_bits(hvlc_ctx* c, const uint32_t* d_in, uint64_t num_words,
+                      const uint32_t* d_codewordlens, uint32_t* d_counts, void* stream)
+{
+    if (!c || !d_codewordlens || (num_words && (!d_in || !d_counts))) return HVLC_ERR_ARG;
+    if (num_words == 0) return HVLC_OK;
+    HVLC_HIP(c, hipSetDevice(c->device));
+    const uint64_t segs = hvlc_num_segments(num_words);
+    uint64_t grid = (segs + 3) / 4;
+    const uint64_t cap = (uint64_t)c->cus * 16;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_segment_bits, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
+                       d_in, num_words, d_codewordlens, d_counts, segs);
+    HVLC_HIP(c, hipGetLastError());
+    return HVLC_OK;
+}
+
+int hvlc_exclusive_scan(hvlc_ctx* c, const uint32_t* d_counts, uint64_t n,
+                        uint64_t* d_offsets, uint64_t* d_total, void* stream)
+{
+    if (!c || (n && (!d_counts || !d_offsets))) return HVLC_ERR_ARG;
+    HVLC_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t tiles = (n + kTileWords - 1) / kTileWords;
+    if (tiles == 0) {
+        if (d_total) HVLC_HIP(c, hipMemsetAsync(d_total, 0, 8, s));
+        return HVLC_OK;
+    }
+    int rc = ensure_workspace(c, tiles);
+    if (rc != HVLC_OK) return rc;
+    EncodeParams p;
+    memset(&p, 0, sizeof(p));
+    p.num_tiles = tiles;
+    fill_granule_ptrs(c, tiles, p);
+    const Layout l = layout_for(tiles);
+    HVLC_HIP(c, hipMemsetAsync(ws_gran(c), 0, l.bytes, s));
+    HVLC_HIP(c, hipMemsetAsync(ws_status(c), 0, 16, s));
+    static int scan_bpc = 0;
+    if (!scan_bpc) scan_bpc = pick_blocks_per_cu(c, k_exclusive_scan, 4);
+    uint64_t grid = (uint64_t)c->cus * (uint64_t)scan_bpc;
+    if (grid > tiles) grid = tiles;
+    hipLaunchKernelGGL(k_exclusive_scan, dim3((unsigned)grid), dim3(kThreads), 0, s, d_counts, n, d_offsets, d_total, p);
+    HVLC_HIP(c, hipGetLastError());
+    return HVLC_OK;
+}
+
+int hvlc_rebase_offsets(hvlc_ctx* c, uint64_t* d_offsets, uint64_t n, uint64_t base_bits, void* stream)
+{
+    if (!c || (n && !d_offsets)) return HVLC_ERR_ARG;
+    if (n == 0 || base_bits == 0) return HVLC_OK;
+    HVLC_HIP(c, hipSetDevice(c->device));
+    uint64_t grid = (n + kThreads - 1) / kThreads;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_rebase, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream, d_offsets, n, base_bits);
+    HVLC_HIP(c, hipGetLastError());
+    return HVLC_OK;
+}
+
+int hvlc_gen_symbols(hvlc_ctx* c, uint8_t* d_out, uint64_t n_bytes, uint64_t seed,
+                     uint64_t first_draw, const uint32_t* d_cdf32, void* stream)
+{
+    if (!c || !d_cdf32 || (n_bytes && !d_out) || (n_bytes & 1u) || ((uintptr_t)d_out & 3u)) return HVLC_ERR_ARG;
+    if (n_bytes == 0) return HVLC_OK;
+    HVLC_HIP(c, hipSetDevice(c->device));
+    const uint64_t words = n_bytes / 4;
+    uint64_t grid = (words + kThreads - 1) / kThreads;
+    if (grid < 1) grid = 1;
+    const uint64_t cap = (uint64_t)c->cus * 32;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_gen_symbols, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
+                       (uint32_t*)d_out, words, n_bytes & 3u, seed, first_draw, d_cdf32);
+    HVLC_HIP(c, hipGetLastError());
+    return HVLC_OK;
+}
+
+int hvlc_histogram(hvlc_ctx* c, const uint8_t* d_data, uint64_t n_bytes, uint64_t* d_hist, void* stream)
+{
+    if (!c || !d_hist || (n_bytes && !d_data) || ((uintptr_t)d_data & 15u)) return HVLC_ERR_ARG;
+    HVLC_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    HVLC_HIP(c, hipMemsetAsync(d_hist, 0, 256 * 8, s));
+    if (n_bytes == 0) return HVLC_OK;
+    // >= 1 block per 64 MiB keeps every 32-bit LDS bin far from overflow; 8 blocks per CU fill the chip
+    uint64_t grid = (uint64_t)c->cus * 8;
+    const uint64_t need = n_bytes / (64ull << 20) + 1;
+    if (grid < need) grid = need;
+    const uint64_t maxb = (n_bytes / 16 + kThreads - 1) / kThreads + 1;
+    if (grid > maxb) grid = maxb;
+    hipLaunchKernelGGL(k_histogram, dim3((unsigned)grid), dim3(kThreads), 0, s, d_data, n_bytes,
+                       (unsigned long long*)d_hist);
+    HVLC_HIP(c, hipGetLastError());
+    return HVLC_OK;
+}
+
+}  // extern "C"

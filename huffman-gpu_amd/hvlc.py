@@ -1,0 +1,321 @@
+"""hvlc.py -- thin host-side binding of libhvlc.so (the C ABI in include/hvlc.h).
+
+PyTorch is used only as plumbing (device buffers, streams); every compute call goes
+through the C ABI into the hand-written gfx950 kernels.  There is NO fallback: if
+libhvlc.so is missing or no GPU is present the calls raise.
+
+The one piece of host logic here that is not a pass-through is code-table
+construction (`huffman_table`, `cdf32_from_counts`), i.e. what load_data.h:31-47 +
+huffTree.h:55-94 do on the host in the reference; it feeds the encoder, it is not on
+the encode path.
+"""
+import ctypes as C
+import heapq
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libhvlc.so")
+SRC = [os.path.join(HERE, "csrc", "hvlc_api.hip")]
+DEPS = SRC + [os.path.join(HERE, "csrc", "hvlc_device.hip.h"), os.path.join(ROOT, "include", "hvlc.h")]
+
+SEGMENT_WORDS = 256
+MAX_CODE_LEN = 31
+
+OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_TABLE, ERR_CAPACITY, ERR_TIMEOUT, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6, -7
+
+EXPORTS = [
+    "hvlc_create", "hvlc_destroy", "hvlc_out_capacity_words", "hvlc_num_segments", "hvlc_encode",
+    "hvlc_finish", "gpu_vlc_encode", "hvlc_segment_bits", "hvlc_exclusive_scan", "hvlc_rebase_offsets",
+    "hvlc_gen_symbols", "hvlc_histogram", "hvlc_get_launch_info", "hvlc_last_hip_error",
+    "hvlc_status_string", "hvlc_version",
+]
+
+
+class HvlcError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        super().__init__(f"{where}: {status_string(status)} ({status})")
+
+
+def build(force=False, verbose=False):
+    """Compile libhvlc.so for gfx950 in-tree with hipcc (cross-compiles without a GPU)."""
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(p) for p in DEPS)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           "-o", LIB_PATH] + SRC
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=HERE)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libhvlc.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    # torch first: its wheel bundles a HIP runtime with the same soname as /opt/rocm's; libhvlc must bind
+    # to the ONE runtime instance that owns the tensors and streams it is handed (a C host links /opt/rocm).
+    import torch  # noqa: F401
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    L.hvlc_create.argtypes = [C.POINTER(vp), i32, u64]
+    L.hvlc_destroy.argtypes = [vp]
+    L.hvlc_out_capacity_words.argtypes = [u64, u32]
+    L.hvlc_out_capacity_words.restype = u64
+    L.hvlc_num_segments.argtypes = [u64]
+    L.hvlc_num_segments.restype = u64
+    L.hvlc_encode.argtypes = [vp, vp, u64, vp, vp, vp, u64, vp, vp, vp]
+    L.hvlc_finish.argtypes = [vp, vp, C.POINTER(u64)]
+    L.gpu_vlc_encode.argtypes = [vp, u32, vp, C.POINTER(u32), vp, vp]
+    L.hvlc_segment_bits.argtypes = [vp, vp, u64, vp, vp, vp]
+    L.hvlc_exclusive_scan.argtypes = [vp, vp, u64, vp, vp, vp]
+    L.hvlc_rebase_offsets.argtypes = [vp, vp, u64, u64, vp]
+    L.hvlc_gen_symbols.argtypes = [vp, vp, u64, u64, u64, vp, vp]
+    L.hvlc_histogram.argtypes = [vp, vp, u64, vp, vp]
+    L.hvlc_get_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.hvlc_last_hip_error.argtypes = [vp]
+    L.hvlc_status_string.argtypes = [i32]
+    L.hvlc_status_string.restype = C.c_char_p
+    L.hvlc_version.restype = C.c_char_p
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int:      # default restype is already int
+            pass
+    _lib = L
+    return L
+
+
+def status_string(s):
+    return lib().hvlc_status_string(int(s)).decode()
+
+
+def out_capacity_words(num_words, max_len):
+    return int(lib().hvlc_out_capacity_words(int(num_words), int(max_len)))
+
+
+def num_segments(num_words):
+    return int(lib().hvlc_num_segments(int(num_words)))
+
+
+def _check(rc, where):
+    if rc != OK:
+        raise HvlcError(rc, where)
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(int(stream))
+
+
+class Encoder:
+    """One hvlc_ctx on one GPU.  `encode` mirrors the reference's
+    encode(input, codeword_table, out_bits, out_offsets) surface on device tensors."""
+
+    def __init__(self, device=0, max_words=1 << 20):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("hvlc needs a GPU: no CPU fallback exists")
+        self.device = int(device)
+        self._ctx = C.c_void_p()
+        _check(lib().hvlc_create(C.byref(self._ctx), self.device, int(max_words)), "hvlc_create")
+
+    def close(self):
+        if self._ctx:
+            lib().hvlc_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- raw pointer API (what a C caller does) ------------------------------------------
+    def encode_ptr(self, d_in, num_words, d_cw, d_cl, d_out, out_cap_words, d_offsets=0, d_total=0, stream=None):
+        rc = lib().hvlc_encode(self._ctx, C.c_void_p(d_in), int(num_words), C.c_void_p(d_cw), C.c_void_p(d_cl),
+                               C.c_void_p(d_out), int(out_cap_words), C.c_void_p(d_offsets or None),
+                               C.c_void_p(d_total or None), _stream_ptr(stream))
+        _check(rc, "hvlc_encode")
+
+    def finish(self, stream=None, check=True):
+        bits = C.c_uint64(0)
+        rc = lib().hvlc_finish(self._ctx, _stream_ptr(stream), C.byref(bits))
+        if check:
+            _check(rc, "hvlc_finish")
+        return int(bits.value), rc
+
+    def launch_info(self):
+        g, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        lib().hvlc_get_launch_info(self._ctx, C.byref(g), C.byref(b), C.byref(c))
+        return {"grid_blocks": g.value, "blocks_per_cu": b.value, "compute_units": c.value}
+
+    # ---- tensor API ----------------------------------------------------------------------
+    def table_to_device(self, codewords, codewordlens):
+        """Host table (two uint32[256]) -> one device int32[512] tensor (codewords | lengths)."""
+        import torch
+        t = np.concatenate([np.asarray(codewords, dtype=np.uint32), np.asarray(codewordlens, dtype=np.uint32)])
+        assert t.shape == (512,)
+        return torch.from_numpy(t.view(np.int32).copy()).to(f"cuda:{self.device}")
+
+    def encode(self, d_in, d_table, max_len=MAX_CODE_LEN, out=None, offsets=None, want_offsets=True, sync=True):
+        """d_in: device tensor of whole uint32 words (any 4-byte dtype or uint8 with numel%4==0).
+        Returns (out_words int32 tensor, offsets int64 tensor or None, total_bits or None)."""
+        import torch
+        nbytes = d_in.numel() * d_in.element_size()
+        assert nbytes % 4 == 0 and d_in.is_contiguous() and d_in.is_cuda
+        W = nbytes // 4
+        cap = out_capacity_words(W, max_len)
+        dev = d_in.device
+        if out is None:
+            out = torch.empty(cap, dtype=torch.int32, device=dev)
+        S = num_segments(W)
+        if want_offsets and offsets is None:
+            offsets = torch.empty(max(S, 1), dtype=torch.int64, device=dev)
+        self.encode_ptr(d_in.data_ptr() if W else 0, W, d_table.data_ptr(), d_table.data_ptr() + 1024,
+                        out.data_ptr(), out.numel(), offsets.data_ptr() if want_offsets else 0, 0)
+        if not sync:
+            return out, offsets, None
+        bits, _ = self.finish()
+        return out, (offsets[:S] if want_offsets else None), bits
+
+    def segment_bits(self, d_in, d_table):
+        import torch
+        W = d_in.numel() * d_in.element_size() // 4
+        counts = torch.empty(max(num_segments(W), 1), dtype=torch.int32, device=d_in.device)
+        _check(lib().hvlc_segment_bits(self._ctx, C.c_void_p(d_in.data_ptr()), W, C.c_void_p(d_table.data_ptr() + 1024),
+                                       C.c_void_p(counts.data_ptr()), _stream_ptr(None)), "hvlc_segment_bits")
+        return counts[: num_segments(W)]
+
+    def exclusive_scan(self, d_counts):
+        import torch
+        n = d_counts.numel()
+        offs = torch.empty(max(n, 1), dtype=torch.int64, device=d_counts.device)
+        total = torch.zeros(1, dtype=torch.int64, device=d_counts.device)
+        _check(lib().hvlc_exclusive_scan(self._ctx, C.c_void_p(d_counts.data_ptr()), n, C.c_void_p(offs.data_ptr()),
+                                         C.c_void_p(total.data_ptr()), _stream_ptr(None)), "hvlc_exclusive_scan")
+        return offs[:n], total
+
+    def rebase_offsets(self, d_offsets, base_bits):
+        _check(lib().hvlc_rebase_offsets(self._ctx, C.c_void_p(d_offsets.data_ptr()), d_offsets.numel(), int(base_bits),
+                                         _stream_ptr(None)), "hvlc_rebase_offsets")
+
+    def gen_symbols(self, n_bytes, seed, cdf32, first_draw=0, out=None):
+        import torch
+        dev = f"cuda:{self.device}"
+        d_cdf = torch.from_numpy(np.asarray(cdf32, dtype=np.uint32).view(np.int32).copy()).to(dev)
+        if out is None:
+            out = torch.empty(n_bytes, dtype=torch.uint8, device=dev)
+        _check(lib().hvlc_gen_symbols(self._ctx, C.c_void_p(out.data_ptr()), int(n_bytes), int(seed), int(first_draw),
+                                      C.c_void_p(d_cdf.data_ptr()), _stream_ptr(None)), "hvlc_gen_symbols")
+        torch.cuda.current_stream().synchronize()     # d_cdf must outlive the kernel
+        return out
+
+    def histogram(self, d_data):
+        import torch
+        h = torch.empty(256, dtype=torch.int64, device=d_data.device)
+        n = d_data.numel() * d_data.element_size()
+        _check(lib().hvlc_histogram(self._ctx, C.c_void_p(d_data.data_ptr()), n, C.c_void_p(h.data_ptr()),
+                                    _stream_ptr(None)), "hvlc_histogram")
+        return h
+
+
+def gpu_vlc_encode(indata, codewords, codewordlens):
+    """Host-buffer drop-in with cpu_vlc_encode's signature (cpuencode.h:4-7).
+    Returns (outdata words incl. the open word, outsize_bytes)."""
+    x = np.ascontiguousarray(indata, dtype=np.uint32)
+    cw = np.ascontiguousarray(codewords, dtype=np.uint32)
+    cl = np.ascontiguousarray(codewordlens, dtype=np.uint32)
+    cap = out_capacity_words(x.size, int(cl.max()) if cl.size else 0)
+    out = np.zeros(cap, dtype=np.uint32)
+    osz = C.c_uint32(0)
+    rc = lib().gpu_vlc_encode(C.c_void_p(x.ctypes.data), x.size, C.c_void_p(out.ctypes.data), C.byref(osz),
+                              C.c_void_p(cw.ctypes.data), C.c_void_p(cl.ctypes.data))
+    _check(rc, "gpu_vlc_encode")
+    return out, int(osz.value)
+
+
+# ------------------------------------------------------------------------------------------
+# host logic: code-table construction (feeds the encoder; not on the encode path)
+# ------------------------------------------------------------------------------------------
+def huffman_lengths(counts, max_len=MAX_CODE_LEN):
+    """Code lengths of a Huffman code for 256 symbol counts (0 = absent symbol -> length 0,
+    as load_data.h leaves unseen symbols).  Lengths above max_len are repaired by the usual
+    Kraft-sum heuristic (flatten the deepest leaves), which is only reached for extremely
+    skewed inputs."""
+    counts = [int(c) for c in counts]
+    live = [(c, s) for s, c in enumerate(counts) if c > 0]
+    lens = [0] * 256
+    if not live:
+        return np.zeros(256, dtype=np.uint32)
+    if len(live) == 1:
+        lens[live[0][1]] = 1
+        return np.array(lens, dtype=np.uint32)
+    heap = [(c, s, (s,)) for c, s in live]
+    heapq.heapify(heap)
+    tie = 256
+    while len(heap) > 1:
+        c0, _, m0 = heapq.heappop(heap)
+        c1, _, m1 = heapq.heappop(heap)
+        for s in m0 + m1:
+            lens[s] += 1
+        heapq.heappush(heap, (c0 + c1, tie, m0 + m1))
+        tie += 1
+    if max(lens) > max_len:
+        order = sorted((s for s in range(256) if lens[s]), key=lambda s: (-lens[s], counts[s]))
+        for s in order:
+            lens[s] = min(lens[s], max_len)
+        kraft = sum(2.0 ** -lens[s] for s in order)
+        i = len(order) - 1
+        while kraft > 1.0 + 1e-12:          # lengthen the shortest codes that can still grow
+            s = order[i]
+            if lens[s] < max_len:
+                kraft -= 2.0 ** -(lens[s] + 1)
+                lens[s] += 1
+            i = i - 1 if i > 0 else len(order) - 1
+    return np.array(lens, dtype=np.uint32)
+
+
+def canonical_codes(lens):
+    """Canonical prefix code for given lengths: codewords right-aligned in `len` bits
+    (the reference's table format, load_data.h:40-47)."""
+    lens = np.asarray(lens, dtype=np.uint32)
+    cw = np.zeros(256, dtype=np.uint32)
+    code, prev = 0, 0
+    for l, s in sorted((int(l), s) for s, l in enumerate(lens) if l > 0):
+        code <<= (l - prev)
+        cw[s] = code
+        code += 1
+        prev = l
+    return cw
+
+
+def huffman_table(counts, max_len=MAX_CODE_LEN):
+    lens = huffman_lengths(counts, max_len)
+    return canonical_codes(lens), lens
+
+
+def cdf32_from_counts(weights):
+    """256-entry 32-bit cumulative table for the synthetic generator: symbol s is drawn when
+    cdf32[s-1] <= u32 < cdf32[s]; the last live entry is pinned to 2^32 (stored as 0xffffffff
+    and treated as always-greater by the generators)."""
+    w = np.asarray(weights, dtype=np.float64)
+    assert w.shape == (256,) and w.sum() > 0
+    c = np.cumsum(w) / w.sum()
+    cdf = np.minimum(np.floor(c * 4294967296.0), 4294967295.0).astype(np.uint64)
+    lastlive = int(np.nonzero(w)[0][-1])
+    cdf[lastlive:] = 0xFFFFFFFF
+    return cdf.astype(np.uint32)

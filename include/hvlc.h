@@ -1,0 +1,150 @@
+/*
+ * hvlc.h -- C ABI of libhvlc.so: MI355X-native (gfx950) variable-length / Huffman
+ * ENCODER, the drop-in for the reference's GPU encode path
+ *
+ *     vlc_encode_kernel_sm64huff  (vlc_kernel_sm64huff.cu:37-160)
+ *   + prescanArray                (scan.cu:228, scanLargeArray_kernel.cu:216-258)
+ *   + pack2                       (pack_kernels.cu:19-52)
+ *
+ * as they are driven from runVLCTest (main_test_cu.cu:130-168), with
+ * cpu_vlc_encode (cpuencode.cpp:12-46) as the bit-exact oracle.
+ *
+ * Plain C: pointers and sizes only, no torch/HIP types in any signature (a
+ * hipStream_t is passed as void*; NULL = the default stream).  All device
+ * pointers are ordinary hipMalloc'd (or torch-allocated) HBM addresses on the
+ * context's device.  Every call returns an hvlc_status (no exit(), unlike the
+ * reference's CUDA_SAFE_CALL, cutil.h:781-789).
+ *
+ * Data formats are the reference's:
+ *   input    uint32 words; symbols are the bytes of each word, MOST significant
+ *            byte first (cpuencode.cpp:28, vlc_kernel_sm64huff.cu:67)
+ *   table    two uint32[256] arrays: codeword (right-aligned in its low `len`
+ *            bits) and length in bits, 0..31; 0 = symbol emits nothing
+ *            (load_data.h:40-47)
+ *   stream   uint32 words, bit 31 first (cpuencode.cpp:34-36); word-for-word what
+ *            cpu_vlc_encode writes, including the zeroed open word at the end
+ *   offsets  exclusive BIT offset of every 256-word (1024-byte) segment, i.e.
+ *            prescanArray's output d_cindex2 (main_test_cu.cu:164) widened to
+ *            uint64 (the reference's uint32 overflows at 512 MiB of output)
+ */
+#ifndef HVLC_H_
+#define HVLC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVLC_SEGMENT_WORDS 256u   /* the reference's block: 256 threads x 1 word (main_test_cu.cu:43) */
+#define HVLC_MAX_CODE_LEN  31u    /* cpuencode.cpp:34: (1<<numbits) limits lengths to 31 */
+
+typedef enum hvlc_status {
+    HVLC_OK            =  0,
+    HVLC_ERR_ARG       = -1,   /* NULL / misaligned pointer, bad size */
+    HVLC_ERR_HIP       = -2,   /* a HIP runtime call failed (hvlc_last_hip_error) */
+    HVLC_ERR_NOMEM     = -3,
+    HVLC_ERR_TABLE     = -4,   /* a length > 31 or a codeword >= 2^len (precondition of cpuencode.cpp:35) */
+    HVLC_ERR_CAPACITY  = -5,   /* stream would not fit out_capacity_words; nothing past it was written */
+    HVLC_ERR_TIMEOUT   = -6,   /* an inter-workgroup wait gave up (workgroups not co-resident); output invalid */
+    HVLC_ERR_NO_DEVICE = -7
+} hvlc_status;
+
+typedef struct hvlc_ctx hvlc_ctx;   /* workspace: replaces preallocBlockSums/deallocBlockSums (scan.cu:67,98) */
+
+/* Create / destroy a context bound to `device`.  max_words sizes the workspace
+ * (16 B per 16 KiB of input); it grows on demand if a later call is larger. */
+int hvlc_create(hvlc_ctx** ctx, int device, uint64_t max_words);
+int hvlc_destroy(hvlc_ctx* ctx);
+
+/* Words the caller must allocate for d_out_bits for `num_words` of input when no
+ * table length exceeds max_len: floor(bits_max/32) + 1, as cpu_vlc_encode needs. */
+uint64_t hvlc_out_capacity_words(uint64_t num_words, uint32_t max_len);
+/* Number of 1024-byte segments (= entries of d_out_offsets) for num_words. */
+uint64_t hvlc_num_segments(uint64_t num_words);
+
+/*
+ * encode(input, codeword_table, out_bits, out_offsets): the whole GPU path of
+ * main_test_cu.cu:141-168 in one asynchronous call on `stream`.
+ *
+ *   d_in            [num_words] uint32, 16-byte aligned; any num_words >= 0 (the
+ *                   reference requires a multiple of 4096 words, load_data.h:19-21)
+ *   d_codewords     [256] uint32   } device copies of the table, as the reference
+ *   d_codewordlens  [256] uint32   } passes them (main_test_cu.cu:142)
+ *   d_out_bits      [out_capacity_words] uint32: receives floor(bits/32)+1 words,
+ *                   identical to cpu_vlc_encode's outdata.  NO zero-fill is needed
+ *                   (the reference memsets it, main_test_cu.cu:162): every word is
+ *                   written exactly once with a plain store.
+ *   d_out_offsets   [hvlc_num_segments] uint64 exclusive bit offsets, or NULL
+ *   d_total_bits    uint64 on the device, or NULL (hvlc_finish returns it too)
+ *
+ * Errors found on the device (table, capacity, timeout) are reported by
+ * hvlc_finish.  Not re-entrant per context (one encode in flight per ctx).
+ */
+int hvlc_encode(hvlc_ctx* ctx,
+                const uint32_t* d_in, uint64_t num_words,
+                const uint32_t* d_codewords, const uint32_t* d_codewordlens,
+                uint32_t* d_out_bits, uint64_t out_capacity_words,
+                uint64_t* d_out_offsets, uint64_t* d_total_bits,
+                void* stream);
+
+/* Wait for the last hvlc_encode on `stream`, return its total bit count and its
+ * device-side status (HVLC_OK / _TABLE / _CAPACITY / _TIMEOUT). */
+int hvlc_finish(hvlc_ctx* ctx, void* stream, uint64_t* total_bits);
+
+/*
+ * Same signature and meaning as the reference's cpu_vlc_encode (cpuencode.h:4-7,
+ * called at main_test_cu.cu:122) but computed on the GPU: HOST buffers in and
+ * out, synchronous.  outdata must hold floor(bits/32)+1 words; *outsize = bytes
+ * rounded up (cpuencode.cpp:44-45).  Returns an hvlc_status (the reference
+ * returns void).  Uses a process-wide context on the current device.
+ */
+int gpu_vlc_encode(unsigned int* indata, unsigned int num_elements,
+                   unsigned int* outdata, unsigned int* outsize,
+                   unsigned int* codewords, unsigned int* codewordlens);
+
+/* ---- the stages of the reference pipeline as separate entry points --------- */
+
+/* Per-segment bit counts: what vlc_encode_kernel_sm64huff stores to outidx[]
+ * (vlc_kernel_sm64huff.cu:119-122; d_cindex at main_test_cu.cu:146).
+ * d_counts [hvlc_num_segments] uint32. */
+int hvlc_segment_bits(hvlc_ctx* ctx, const uint32_t* d_in, uint64_t num_words,
+                      const uint32_t* d_codewordlens, uint32_t* d_counts, void* stream);
+
+/* Exclusive prefix sum uint32[n] -> uint64[n] (+ optional total): replaces
+ * preallocBlockSums + prescanArray + deallocBlockSums (main_test_cu.cu:160-168)
+ * with a single-launch wavefront-hierarchical scan. */
+int hvlc_exclusive_scan(hvlc_ctx* ctx, const uint32_t* d_counts, uint64_t n,
+                        uint64_t* d_offsets, uint64_t* d_total, void* stream);
+
+/* Multi-GPU stitch: add a shard's base bit offset (the exclusive prefix of the
+ * per-shard totals exchanged over RCCL) to its local segment offsets. */
+int hvlc_rebase_offsets(hvlc_ctx* ctx, uint64_t* d_offsets, uint64_t n,
+                        uint64_t base_bits, void* stream);
+
+/* ---- utilities used by the harness / benchmarks ---------------------------- */
+
+/* Deterministic synthetic symbol stream on the device:
+ * r = splitmix64(seed + first_draw + j), two symbols per draw through a 256-entry
+ * 32-bit cumulative table d_cdf32.  n_bytes even, d_out 4-byte aligned. */
+int hvlc_gen_symbols(hvlc_ctx* ctx, uint8_t* d_out, uint64_t n_bytes, uint64_t seed,
+                     uint64_t first_draw, const uint32_t* d_cdf32, void* stream);
+
+/* 256-bin byte histogram on the device (input to code-table construction; the
+ * reference's histo_kernel, hist.cu:34-52, without its windowing bug :98-102).
+ * d_hist [256] uint64, overwritten. */
+int hvlc_histogram(hvlc_ctx* ctx, const uint8_t* d_data, uint64_t n_bytes,
+                   uint64_t* d_hist, void* stream);
+
+/* Introspection: launch geometry chosen for this device (grid, blocks per CU,
+ * CUs) and the last HIP error code seen by this context. */
+int hvlc_get_launch_info(hvlc_ctx* ctx, int* grid_blocks, int* blocks_per_cu, int* compute_units);
+int hvlc_last_hip_error(hvlc_ctx* ctx);
+const char* hvlc_status_string(int status);
+const char* hvlc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVLC_H_ */

@@ -1,0 +1,350 @@
+"""-m gpu: parity of the HIP encode path (through the C ABI) against the CPU oracle, the golden
+vectors the reference produced, and -- at BASELINE.json's full sizes -- size-independent
+properties.  Bar: bit-exact (integer/bit work), every word of the stream and every offset."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import hvlc
+import oracle_lib as O
+from util import extract_bits, random_table, synth_on_device
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def enc():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (the product has no CPU fallback)"
+    e = hvlc.Encoder(0, 1 << 22)
+    yield e
+    e.close()
+
+
+def _dev(x_u32):
+    return torch.from_numpy(np.ascontiguousarray(x_u32, dtype=np.uint32).view(np.int32).copy()).cuda()
+
+
+def _check(enc, x, cw, cl, what=""):
+    """Encode x on the GPU and compare stream, total bits and segment offsets with the oracle."""
+    x = np.ascontiguousarray(x, dtype=np.uint32)
+    d_tab = enc.table_to_device(cw, cl)
+    out, offs, bits = enc.encode(_dev(x), d_tab, max_len=int(cl.max()) if cl.size else 0)
+    ref, rbits = O.encode(x, cw, cl)
+    assert bits == rbits, (what, bits, rbits)
+    got = out[: bits // 32 + 1].cpu().numpy().view(np.uint32)
+    if not np.array_equal(got, ref):
+        bad = np.nonzero(got != ref)[0]
+        raise AssertionError(f"{what}: {bad.size} words differ, first at {bad[0]}: "
+                             f"{got[bad[0]]:08x} != {ref[bad[0]]:08x} (of {ref.size})")
+    _, roffs, _ = O.segment_offsets(x, cl)
+    assert np.array_equal(offs.cpu().numpy().view(np.uint64), roffs), what
+    return bits
+
+
+def test_g1_golden(enc, golden):
+    """The reference's own end-to-end case (run:1, main_test_cu.cu:159-172): shipped file + its table."""
+    m = golden["meta"]["G1"]
+    x = np.tile(golden["period"], 4).view(np.uint32)
+    d_tab = enc.table_to_device(golden["cw"], golden["cl"])
+    out, offs, bits = enc.encode(_dev(x), d_tab, max_len=21)
+    assert bits == m["total_bits"] == 2330672
+    osz = (bits + 7) // 8
+    got = out[: m["num_ints"]].cpu().numpy().view(np.uint32)
+    assert hashlib.sha256(got.tobytes()[:osz]).hexdigest() == m["out_sha256"]
+    assert hashlib.sha256(got.tobytes()).hexdigest() == m["out_words_sha256"]
+    assert [int(v) for v in got[:4]] == m["first_words"]
+    o = offs.cpu().numpy().view(np.uint64)
+    assert [int(v) for v in o[:4]] == [0, 2275, 4609, 6951] and int(o[-1]) == 2328317
+    assert np.array_equal(np.diff(o).astype(np.uint32), golden["seg_counts"][:-1])
+
+
+def test_g1_period_golden(enc, golden):
+    m = golden["meta"]["G1p"]
+    x = golden["period"].view(np.uint32)
+    out, _, bits = enc.encode(_dev(x), enc.table_to_device(golden["cw"], golden["cl"]), max_len=21)
+    osz = (bits + 7) // 8
+    assert osz == m["outsize"]
+    got = out[: (osz + 3) // 4].cpu().numpy().view(np.uint32)
+    assert hashlib.sha256(got.tobytes()[:osz]).hexdigest() == m["out_sha256"]
+
+
+@pytest.mark.parametrize("name", ["K1", "K2", "K3"])
+def test_kat(enc, golden, name):
+    k = golden["meta"]["KAT"][name]
+    if k["table"] == "generateCodewords":
+        cw, cl = O.generate_codewords(256)
+    else:
+        cw = np.zeros(256, dtype=np.uint32)
+        cl = np.zeros(256, dtype=np.uint32)
+        for s, (c, l) in k["table"].items():
+            cw[int(s)], cl[int(s)] = c, l
+    x = np.array(k["input"], dtype=np.uint32)
+    out, _, bits = enc.encode(_dev(x), enc.table_to_device(cw, cl), max_len=int(cl.max()))
+    assert (bits + 7) // 8 == k["outsize"]
+    assert [int(v) for v in out[: (k["outsize"] + 3) // 4].cpu().numpy().view(np.uint32)] == k["words"]
+    # and through the host-buffer drop-in with cpu_vlc_encode's signature
+    o2, osz = hvlc.gpu_vlc_encode(x, cw, cl)
+    assert osz == k["outsize"] and [int(v) for v in o2[: (osz + 3) // 4]] == k["words"]
+
+
+def test_reference_diff_vectors(enc, golden):
+    """Expected words came from the reference itself (tests/golden/make_golden.py)."""
+    vec = golden["vec"]
+    for c in golden["meta"]["diff_cases"]:
+        if c["kind"] == "unmasked":
+            continue            # violates the table precondition; see test_bad_table
+        i = c["id"]
+        cl = vec[f"cl{i}"]
+        out, _, bits = enc.encode(_dev(vec[f"in{i}"]), enc.table_to_device(vec[f"cw{i}"], cl), max_len=int(cl.max()))
+        assert (bits + 7) // 8 == c["outsize"], c
+        exp = vec[f"out{i}"]
+        assert np.array_equal(out[: exp.size].cpu().numpy().view(np.uint32), exp), c
+
+
+@pytest.mark.parametrize("nwords", [1, 2, 63, 255, 256, 257, 1023, 4095, 4096, 4097, 12345, 65536, 65536 * 3 + 17])
+@pytest.mark.parametrize("kind", ["any", "short", "long"])
+def test_ragged_sizes_vs_oracle(enc, nwords, kind):
+    rng = np.random.default_rng(nwords * 7 + len(kind))
+    cw, cl = random_table(rng, kind)
+    x = rng.integers(0, 1 << 32, nwords, dtype=np.uint64).astype(np.uint32)
+    _check(enc, x, cw, cl, f"{kind}/{nwords}")
+
+
+@pytest.mark.parametrize("kind", ["all31", "alt1_31", "zeros", "allzero", "len4", "len16", "len17"])
+def test_adversarial_tables(enc, kind):
+    """All-31-bit codes (496 bits per 16 symbols: general path), alternating 1/31, mostly/all
+    length-0 symbols (carry chains through empty tiles), 16 x 4 = exactly 64 bits, 16/17-bit codes."""
+    rng = np.random.default_rng(hash(kind) & 0xFFFF)
+    cw, cl = random_table(rng, kind)
+    for nwords in (4096 * 5 + 100, 300):
+        x = rng.integers(0, 1 << 32, nwords, dtype=np.uint64).astype(np.uint32)
+        _check(enc, x, cw, cl, f"{kind}/{nwords}")
+
+
+def test_sparse_bits_cross_tile_carry(enc):
+    """Only one symbol in ~2000 emits bits: most tiles hold fewer than 31 bits, so the 31-bit
+    carry has to travel through many tiles (and through tiles with no bits at all)."""
+    rng = np.random.default_rng(5)
+    cl = np.zeros(256, dtype=np.uint32)
+    cw = np.zeros(256, dtype=np.uint32)
+    cl[200], cw[200] = 7, 0b1010011
+    cl[201], cw[201] = 1, 1
+    x8 = np.zeros(4096 * 4 * 40, dtype=np.uint8)
+    hits = rng.choice(x8.size, x8.size // 2000, replace=False)
+    x8[hits] = rng.choice([200, 201], hits.size)
+    _check(enc, x8.view(np.uint32), cw, cl, "sparse")
+
+
+def test_mixed_fast_and_general_tiles(enc, golden):
+    """Mostly short codes with rare 31-bit codes: some tiles take the general path, neighbours
+    the fast path, so carries cross between the two."""
+    rng = np.random.default_rng(11)
+    cl = np.full(256, 2, dtype=np.uint32)
+    cl[250:] = 31
+    cw = (rng.integers(0, 1 << 32, 256, dtype=np.uint64).astype(np.uint64)
+          & ((np.uint64(1) << cl.astype(np.uint64)) - np.uint64(1))).astype(np.uint32)
+    x8 = rng.integers(0, 250, 4096 * 4 * 24, dtype=np.int64).astype(np.uint8)
+    for t in (3, 4, 10, 23):                                    # bursts of long codes in four tiles
+        x8[t * 16384 + 100: t * 16384 + 140] = 251
+    _check(enc, x8.view(np.uint32), cw, cl, "mixed")
+
+
+def test_empty_input(enc):
+    cw, cl = O.generate_codewords(256)
+    d_tab = enc.table_to_device(cw, cl)
+    out = torch.full((4,), -1, dtype=torch.int32, device="cuda")
+    enc.encode_ptr(0, 0, d_tab.data_ptr(), d_tab.data_ptr() + 1024, out.data_ptr(), 4)
+    bits, rc = enc.finish()
+    assert bits == 0 and rc == 0
+    assert out.cpu().tolist() == [0, -1, -1, -1]               # exactly the one open word (cpuencode.cpp:17)
+
+
+def test_word_boundary_end_writes_trailing_zero_word(enc):
+    cw, cl = random_table(np.random.default_rng(3), "len4")
+    x = ((np.arange(4096 + 8, dtype=np.uint64) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    d_tab = enc.table_to_device(cw, cl)
+    out = torch.full((x.size * 16 // 32 + 3,), -1, dtype=torch.int32, device="cuda")
+    enc.encode_ptr(_dev(x).data_ptr(), x.size, d_tab.data_ptr(), d_tab.data_ptr() + 1024, out.data_ptr(), out.numel())
+    bits, _ = enc.finish()
+    assert bits == x.size * 16 and bits % 32 == 0
+    o = out.cpu().numpy()
+    assert o[bits // 32] == 0 and o[bits // 32 + 1] == -1 and o[bits // 32 + 2] == -1
+    ref, _ = O.encode(x.astype(np.uint32), cw, cl)
+    assert np.array_equal(o[: bits // 32 + 1].view(np.uint32), ref)
+
+
+def test_no_zero_fill_contract(enc, golden):
+    """d_out_bits pre-filled with garbage: every word of the stream is overwritten, nothing after it is touched."""
+    x = golden["period"].view(np.uint32)[:50000]
+    d_tab = enc.table_to_device(golden["cw"], golden["cl"])
+    ref, rbits = O.encode(x, golden["cw"], golden["cl"])
+    out = torch.full((ref.size + 64,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    enc.encode_ptr(_dev(x).data_ptr(), x.size, d_tab.data_ptr(), d_tab.data_ptr() + 1024, out.data_ptr(), out.numel())
+    bits, _ = enc.finish()
+    o = out.cpu().numpy().view(np.uint32)
+    assert bits == rbits and np.array_equal(o[: ref.size], ref) and (o[ref.size:] == 0x5A5A5A5A).all()
+
+
+def test_bad_table_is_reported(enc):
+    cw, cl = O.generate_codewords(256)
+    cl2 = cl.copy(); cl2[9] = 32
+    x = np.arange(1000, dtype=np.uint32)
+    d_in = _dev(x)
+    out = torch.empty(hvlc.out_capacity_words(x.size, 31), dtype=torch.int32, device="cuda")
+    for bad_cw, bad_cl in ((cw, cl2), (cw | np.uint32(1 << 20), cl)):
+        d_tab = enc.table_to_device(bad_cw, bad_cl)
+        enc.encode_ptr(d_in.data_ptr(), x.size, d_tab.data_ptr(), d_tab.data_ptr() + 1024, out.data_ptr(), out.numel())
+        _, rc = enc.finish(check=False)
+        assert rc == hvlc.ERR_TABLE
+
+
+def test_capacity_is_enforced_without_overrun(enc, golden):
+    x = golden["period"].view(np.uint32)
+    d_tab = enc.table_to_device(golden["cw"], golden["cl"])
+    cap = 1000
+    out = torch.full((cap + 256,), 0x77, dtype=torch.int32, device="cuda")
+    enc.encode_ptr(_dev(x).data_ptr(), x.size, d_tab.data_ptr(), d_tab.data_ptr() + 1024, out.data_ptr(), cap)
+    _, rc = enc.finish(check=False)
+    assert rc == hvlc.ERR_CAPACITY
+    assert (out[cap:].cpu().numpy() == 0x77).all()
+    ref, _ = O.encode(x, golden["cw"], golden["cl"])
+    assert np.array_equal(out[:cap].cpu().numpy().view(np.uint32), ref[:cap])    # the part that fits is right
+
+
+def test_argument_checks(enc):
+    cw, cl = O.generate_codewords(256)
+    d_tab = enc.table_to_device(cw, cl)
+    buf = torch.zeros(64, dtype=torch.int32, device="cuda")
+    with pytest.raises(hvlc.HvlcError):      # misaligned input
+        enc.encode_ptr(buf.data_ptr() + 4, 8, d_tab.data_ptr(), d_tab.data_ptr() + 1024, buf.data_ptr(), 64)
+    with pytest.raises(hvlc.HvlcError):      # no output
+        enc.encode_ptr(buf.data_ptr(), 8, d_tab.data_ptr(), d_tab.data_ptr() + 1024, 0, 64)
+
+
+def test_repeatable_and_idempotent(enc, golden):
+    """Two runs into the same buffers give identical bytes (no state leaks between launches)."""
+    x = np.tile(golden["period"], 2).view(np.uint32)
+    d_in = _dev(x); d_tab = enc.table_to_device(golden["cw"], golden["cl"])
+    o1, f1, b1 = enc.encode(d_in, d_tab, max_len=21)
+    a = o1[: b1 // 32 + 1].clone(); fa = f1.clone()
+    for _ in range(5):
+        o2, f2, b2 = enc.encode(d_in, d_tab, max_len=21, out=o1, offsets=f1)
+        assert b2 == b1 and torch.equal(o2[: b1 // 32 + 1], a) and torch.equal(f2, fa)
+
+
+def test_stage_entry_points(enc, golden):
+    """hvlc_segment_bits (A1's outidx) and hvlc_exclusive_scan (A3) as separate stages."""
+    x = np.tile(golden["period"], 4).view(np.uint32)
+    d_in = _dev(x); d_tab = enc.table_to_device(golden["cw"], golden["cl"])
+    counts = enc.segment_bits(d_in, d_tab)
+    assert np.array_equal(counts.cpu().numpy().view(np.uint32), golden["seg_counts"])
+    offs, total = enc.exclusive_scan(counts)
+    _, roffs, rtotal = O.segment_offsets(x, golden["cl"])
+    assert np.array_equal(offs.cpu().numpy().view(np.uint64), roffs) and int(total.item()) == rtotal
+    enc.rebase_offsets(offs, 1 << 40)
+    assert np.array_equal(offs.cpu().numpy().view(np.uint64), roffs + np.uint64(1 << 40))
+
+
+@pytest.mark.parametrize("n", [1, 255, 4096, 4097, 4096 * 64 + 5, 4096 * 64 * 3 + 1, 5_000_000])
+def test_exclusive_scan_sizes(enc, n):
+    rng = np.random.default_rng(n)
+    c = rng.integers(0, 1 << 32 if n < 5000 else 40000, n, dtype=np.uint64).astype(np.uint32)
+    offs, total = enc.exclusive_scan(_dev(c))
+    ref = np.concatenate([[0], np.cumsum(c.astype(np.uint64))])
+    assert np.array_equal(offs.cpu().numpy().view(np.uint64), ref[:-1]) and int(total.item()) == int(ref[-1])
+
+
+def test_generator_and_histogram_match_oracle(enc, golden):
+    from util import dist_weights
+    for name in ("H2.2", "H4.0", "H1.0"):
+        cdf = hvlc.cdf32_from_counts(dist_weights(name, golden["period"]))
+        d = enc.gen_symbols(1 << 20, 0x5EED0002, cdf, first_draw=12345)
+        ref = O.gen_symbols(1 << 20, 0x5EED0002, cdf, first_draw=12345)
+        assert np.array_equal(d.cpu().numpy(), ref), name
+        h = enc.histogram(d).cpu().numpy()
+        assert np.array_equal(h.astype(np.uint64), O.histogram(ref)), name
+    d = enc.gen_symbols(1 << 20, 1, cdf)[: (1 << 20) - 16 + 6]
+    # histogram with a ragged tail
+    buf = torch.empty((1 << 20) + 16, dtype=torch.uint8, device="cuda")
+    buf[: d.numel()] = d
+    h = enc.histogram(buf[: d.numel()]).cpu().numpy()
+    assert np.array_equal(h.astype(np.uint64), O.histogram(d.cpu().numpy()))
+
+
+# ---- BASELINE.json configs ----------------------------------------------------------------------
+
+def test_config2_256MiB_H22_full_compare(enc, golden):
+    """configs[1]: 256 MiB synthetic H~2.2 stream, compared word for word with the oracle."""
+    n = 256 << 20
+    d_in, cw, cl, hist = synth_on_device(enc, "H2.2", n, golden["period"])
+    out, offs, bits = enc.encode(d_in, enc.table_to_device(cw, cl), max_len=int(cl.max()))
+    assert bits == int((hist * cl).sum())
+    x = d_in.cpu().numpy().view(np.uint32)
+    ref, rbits = O.encode(x, cw, cl)
+    assert bits == rbits
+    assert torch.equal(out[: bits // 32 + 1].cpu(), torch.from_numpy(ref.view(np.int32)))
+    _, roffs, _ = O.segment_offsets(x, cl)
+    assert np.array_equal(offs.cpu().numpy().view(np.uint64), roffs)
+    assert 0.27 < bits / 8 / n < 0.29
+
+
+def _check_windows(enc, d_in, out, offs, bits, cw, cl, hist, windows, rng):
+    """Full-size properties: total == sum(hist*len); offsets strictly consistent with the device
+    segment counts; and the stream bits of randomly chosen segment windows equal the oracle's
+    encoding of just those segments (concatenative property)."""
+    assert bits == int((hist * cl.astype(np.uint64)).sum())
+    counts = enc.segment_bits(d_in, enc.table_to_device(cw, cl))
+    S = counts.numel()
+    o64 = offs[:S]
+    assert int(o64[0].item()) == 0
+    assert torch.equal(o64[1:] - o64[:-1], counts[:-1].to(torch.int64))
+    assert int(o64[-1].item()) + int(counts[-1].item()) == bits
+    for _ in range(windows):
+        nseg = int(rng.integers(1, 600))
+        s0 = int(rng.integers(0, S - nseg))
+        x = d_in.view(torch.int32)[s0 * 256:(s0 + nseg) * 256].cpu().numpy().view(np.uint32)
+        ref, rbits = O.encode(x, cw, cl)
+        b0 = int(o64[s0].item())
+        b1 = int(o64[s0 + nseg].item()) if s0 + nseg < S else bits
+        assert b1 - b0 == rbits
+        w0 = b0 // 32
+        chunk = out[w0: w0 + rbits // 32 + 3].cpu().numpy().view(np.uint32)
+        got = extract_bits(chunk, b0 - 32 * w0, rbits)
+        assert np.array_equal(got, ref[: got.size]), (s0, nseg)
+    # the last segments up to the very end of the stream, including the zero-padded open word
+    x = d_in.view(torch.int32)[(S - 3) * 256:].cpu().numpy().view(np.uint32)
+    ref, rbits = O.encode(x, cw, cl)
+    b0 = int(o64[S - 3].item())
+    chunk = out[b0 // 32: bits // 32 + 1].cpu().numpy().view(np.uint32)
+    got = extract_bits(chunk, b0 % 32, rbits)
+    assert np.array_equal(got, ref[: got.size])
+    assert (int(out[bits // 32].item()) & 0xFFFFFFFF) & ((1 << (32 - bits % 32)) - 1) == 0
+
+
+@pytest.mark.parametrize("name", ["H4.0", "H1.0", "H2.2"])
+def test_config_4GiB_properties(enc, golden, name):
+    """configs[2], [3] and the north-star 4 GiB H~2.2 case: more than 2^32 output bits for H4.0
+    (64-bit offsets), 4 194 304 segments / 4096 groups (multi-window look-back), long max codeword
+    and heavy LDS contention for H1.0."""
+    n = 4 << 30
+    d_in, cw, cl, hist = synth_on_device(enc, name, n, golden["period"])
+    out, offs, bits = enc.encode(d_in, enc.table_to_device(cw, cl), max_len=int(cl.max()))
+    if name == "H4.0":
+        assert bits == 4 * n and bits > 1 << 32 and set(np.unique(cl)) == {0, 4}
+    if name == "H1.0":
+        assert int(cl.max()) >= 23
+    _check_windows(enc, d_in, out, offs, bits, cw, cl, hist, 24, np.random.default_rng(1))
+    del out, offs, d_in
+    torch.cuda.empty_cache()
+
+
+def test_general_path_large(enc):
+    """64 MiB of uniform bytes (every code 8 bits: every lane-row holds 128 bits) -> general path throughout."""
+    n = 64 << 20
+    d_in, cw, cl, hist = synth_on_device(enc, "H8.0", n)
+    assert set(np.unique(cl)) == {8}
+    out, offs, bits = enc.encode(d_in, enc.table_to_device(cw, cl), max_len=8)
+    assert bits == 8 * n
+    _check_windows(enc, d_in, out, offs, bits, cw, cl, hist, 8, np.random.default_rng(2))

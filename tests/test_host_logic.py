@@ -1,0 +1,67 @@
+"""-m "not gpu": host-side table construction (the repo's own Huffman builder that feeds the
+benchmarks; reference counterpart huffTree.h:55-94 + load_data.h:40-47) and test helpers."""
+import numpy as np
+
+import hvlc
+import oracle_lib as O
+from util import extract_bits, dist_weights
+
+
+def _prefix_free(cw, cl):
+    codes = sorted((format(int(c), "b").zfill(int(l)) for c, l in zip(cw, cl) if l > 0))
+    return all(not b.startswith(a) for a, b in zip(codes, codes[1:]))
+
+
+def test_huffman_matches_reference_total_on_g1(golden):
+    hist = np.bincount(np.tile(golden["period"], 4), minlength=256)
+    cw, cl = hvlc.huffman_table(hist)
+    assert _prefix_free(cw, cl)
+    # any Huffman code is optimal: same total bits as the reference's table, whatever the tie-breaking
+    assert int((hist * cl).sum()) == int((hist * golden["cl"]).sum()) == 2330672
+    assert ((cl > 0) == (hist > 0)).all()
+    assert abs(sum(2.0 ** -int(l) for l in cl if l) - 1.0) < 1e-12
+
+
+def test_huffman_degenerate_and_limited():
+    cw, cl = hvlc.huffman_table(np.zeros(256))
+    assert cl.sum() == 0
+    h = np.zeros(256); h[7] = 5
+    cw, cl = hvlc.huffman_table(h)
+    assert cl[7] == 1 and cl.sum() == 1
+    fib = np.zeros(256)
+    a, b = 1, 1
+    for i in range(60):
+        fib[i] = a
+        a, b = b, a + b
+    cw, cl = hvlc.huffman_table(fib)
+    assert cl.max() <= 31 and _prefix_free(cw, cl)
+    assert sum(2.0 ** -int(l) for l in cl if l) <= 1.0 + 1e-12
+    assert (cw < (np.uint64(1) << cl.astype(np.uint64))).all()
+
+
+def test_named_distributions_have_expected_shape(golden):
+    w = dist_weights("H1.0")
+    p = w / w.sum()
+    H = -(p[p > 0] * np.log2(p[p > 0])).sum()
+    assert 0.9 < H < 1.1
+    cw, cl = hvlc.huffman_table((p * 2 ** 40).astype(np.uint64))
+    assert list(cl[:25]) == list(range(1, 25)) + [24]
+    w4 = dist_weights("H4.0")
+    assert (w4 > 0).sum() == 16
+    cdf = hvlc.cdf32_from_counts(w4)
+    x = O.gen_symbols(1 << 16, 0x5EED0003, cdf)
+    assert set(np.unique(x)) <= set(range(3, 256, 16))
+    wg = dist_weights("H2.2", golden["period"])
+    assert (wg > 0).sum() == 32
+
+
+def test_extract_bits_roundtrip():
+    rng = np.random.default_rng(1)
+    w = rng.integers(0, 1 << 32, 64, dtype=np.uint64).astype(np.uint32)
+    bits = "".join(format(int(v), "032b") for v in w)
+    for start, n in [(0, 32), (5, 64), (31, 1), (33, 95), (100, 0), (640, 1000)]:
+        got = extract_bits(w, start, n)
+        s = bits[start:start + n]
+        s = s + "0" * (-len(s) % 32)
+        exp = [int(s[i:i + 32], 2) for i in range(0, len(s), 32)]
+        assert [int(v) for v in got] == exp
