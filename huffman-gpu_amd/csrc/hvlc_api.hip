@@ -33,6 +33,10 @@ struct hvlc_ctx {
     uint64_t  timeout_ticks = 200000000ull;   // 2 s of the 100 MHz real-time counter
     // pinned host mirror for hvlc_finish
     uint32_t* h_status      = nullptr;   // [0] flags, [2..3] total bits
+    // optional event pairs around k_encode (hvlc_profile_begin / _collect)
+    hipEvent_t* ev          = nullptr;
+    int       ev_cap        = 0;
+    int       ev_used       = 0;
 };
 
 namespace {
@@ -182,6 +186,7 @@ int hvlc_destroy(hvlc_ctx* c)
     (void)hipDeviceSynchronize();
     if (c->ws) (void)hipFree(c->ws);
     if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->ev) { for (int i = 0; i < 2 * c->ev_cap; ++i) (void)hipEventDestroy(c->ev[i]); delete[] c->ev; }
     delete c;
     return HVLC_OK;
 }
@@ -240,8 +245,41 @@ int hvlc_encode(hvlc_ctx* c,
     uint64_t grid = (uint64_t)c->cus * (uint64_t)c->blocks_per_cu;
     if (grid > tiles) grid = tiles;
     c->last_grid = (int)grid;
+    const bool prof = c->ev && c->ev_used < c->ev_cap;
+    if (prof) HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used], s));
     hipLaunchKernelGGL(k_encode, dim3((unsigned)grid), dim3(kThreads), 0, s, p);
     HVLC_HIP(c, hipGetLastError());
+    if (prof) { HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used + 1], s)); c->ev_used++; }
+    return HVLC_OK;
+}
+
+int hvlc_profile_begin(hvlc_ctx* c, int max_launches)
+{
+    if (!c || max_launches < 1 || max_launches > 4096) return HVLC_ERR_ARG;
+    HVLC_HIP(c, hipSetDevice(c->device));
+    if (c->ev) { for (int i = 0; i < 2 * c->ev_cap; ++i) (void)hipEventDestroy(c->ev[i]); delete[] c->ev; c->ev = nullptr; }
+    c->ev = new (std::nothrow) hipEvent_t[2 * max_launches];
+    if (!c->ev) return HVLC_ERR_NOMEM;
+    for (int i = 0; i < 2 * max_launches; ++i) HVLC_HIP(c, hipEventCreate(&c->ev[i]));
+    c->ev_cap = max_launches;
+    c->ev_used = 0;
+    return HVLC_OK;
+}
+
+int hvlc_profile_collect(hvlc_ctx* c, float* ms, int* count)
+{
+    if (!c || !ms || !count) return HVLC_ERR_ARG;
+    int n = 0;
+    if (c->ev) {
+        for (; n < c->ev_used; ++n) {
+            HVLC_HIP(c, hipEventSynchronize(c->ev[2 * n + 1]));
+            HVLC_HIP(c, hipEventElapsedTime(&ms[n], c->ev[2 * n], c->ev[2 * n + 1]));
+        }
+        for (int i = 0; i < 2 * c->ev_cap; ++i) (void)hipEventDestroy(c->ev[i]);
+        delete[] c->ev;
+        c->ev = nullptr; c->ev_cap = 0; c->ev_used = 0;
+    }
+    *count = n;
     return HVLC_OK;
 }
 
@@ -357,6 +395,20 @@ int hvlc_rebase_offsets(hvlc_ctx* c, uint64_t* d_offsets, uint64_t n, uint64_t b
     uint64_t grid = (n + kThreads - 1) / kThreads;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_rebase, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream, d_offsets, n, base_bits);
+    HVLC_HIP(c, hipGetLastError());
+    return HVLC_OK;
+}
+
+int hvlc_rebase_offsets_dev(hvlc_ctx* c, uint64_t* d_offsets, uint64_t n,
+                            const uint64_t* d_shard_totals, int rank, void* stream)
+{
+    if (!c || (n && !d_offsets) || !d_shard_totals || rank < 0 || rank > 4096) return HVLC_ERR_ARG;
+    if (n == 0 || rank == 0) return HVLC_OK;
+    HVLC_HIP(c, hipSetDevice(c->device));
+    uint64_t grid = (n + kThreads - 1) / kThreads;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_rebase_dev, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
+                       d_offsets, n, d_shard_totals, rank);
     HVLC_HIP(c, hipGetLastError());
     return HVLC_OK;
 }

@@ -611,6 +611,15 @@ __global__ void __launch_bounds__(kThreads) k_rebase(uint64_t* offs, uint64_t n,
         offs[i] += base;
 }
 
+// base = exclusive prefix of the all-gathered per-shard totals, computed by every thread (rank <= a few)
+__global__ void __launch_bounds__(kThreads) k_rebase_dev(uint64_t* offs, uint64_t n, const uint64_t* totals, int rank)
+{
+    uint64_t base = 0;
+    for (int r = 0; r < rank; ++r) base += totals[r];
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads)
+        offs[i] += base;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Harness utilities: synthetic symbol generator and byte histogram.
 // ---------------------------------------------------------------------------------------------

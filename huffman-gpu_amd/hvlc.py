@@ -30,6 +30,7 @@ OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_TABLE, ERR_CAPACITY, ERR_TIMEOUT, ERR_NO_DE
 EXPORTS = [
     "hvlc_create", "hvlc_destroy", "hvlc_out_capacity_words", "hvlc_num_segments", "hvlc_encode",
     "hvlc_finish", "gpu_vlc_encode", "hvlc_segment_bits", "hvlc_exclusive_scan", "hvlc_rebase_offsets",
+    "hvlc_rebase_offsets_dev", "hvlc_profile_begin", "hvlc_profile_collect",
     "hvlc_gen_symbols", "hvlc_histogram", "hvlc_get_launch_info", "hvlc_last_hip_error",
     "hvlc_status_string", "hvlc_version",
 ]
@@ -82,6 +83,9 @@ def lib():
     L.hvlc_segment_bits.argtypes = [vp, vp, u64, vp, vp, vp]
     L.hvlc_exclusive_scan.argtypes = [vp, vp, u64, vp, vp, vp]
     L.hvlc_rebase_offsets.argtypes = [vp, vp, u64, u64, vp]
+    L.hvlc_rebase_offsets_dev.argtypes = [vp, vp, u64, vp, i32, vp]
+    L.hvlc_profile_begin.argtypes = [vp, i32]
+    L.hvlc_profile_collect.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
     L.hvlc_gen_symbols.argtypes = [vp, vp, u64, u64, u64, vp, vp]
     L.hvlc_histogram.argtypes = [vp, vp, u64, vp, vp]
     L.hvlc_get_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
@@ -212,6 +216,20 @@ class Encoder:
     def rebase_offsets(self, d_offsets, base_bits):
         _check(lib().hvlc_rebase_offsets(self._ctx, C.c_void_p(d_offsets.data_ptr()), d_offsets.numel(), int(base_bits),
                                          _stream_ptr(None)), "hvlc_rebase_offsets")
+
+    def rebase_offsets_dev(self, d_offsets, d_shard_totals, rank):
+        _check(lib().hvlc_rebase_offsets_dev(self._ctx, C.c_void_p(d_offsets.data_ptr()), d_offsets.numel(),
+                                             C.c_void_p(d_shard_totals.data_ptr()), int(rank), _stream_ptr(None)),
+               "hvlc_rebase_offsets_dev")
+
+    def profile_begin(self, max_launches):
+        _check(lib().hvlc_profile_begin(self._ctx, int(max_launches)), "hvlc_profile_begin")
+
+    def profile_collect(self, max_launches):
+        ms = (C.c_float * max_launches)()
+        n = C.c_int(0)
+        _check(lib().hvlc_profile_collect(self._ctx, ms, C.byref(n)), "hvlc_profile_collect")
+        return [float(ms[i]) for i in range(n.value)]
 
     def gen_symbols(self, n_bytes, seed, cdf32, first_draw=0, out=None):
         import torch

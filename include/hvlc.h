@@ -123,7 +123,20 @@ int hvlc_exclusive_scan(hvlc_ctx* ctx, const uint32_t* d_counts, uint64_t n,
 int hvlc_rebase_offsets(hvlc_ctx* ctx, uint64_t* d_offsets, uint64_t n,
                         uint64_t base_bits, void* stream);
 
+/* Same, with the base computed on the device: base = sum of d_shard_totals[0..rank),
+ * where d_shard_totals is the all-gathered array of per-shard total bit counts (one
+ * uint64 per rank, e.g. the output of ncclAllGather over xGMI).  No host round trip. */
+int hvlc_rebase_offsets_dev(hvlc_ctx* ctx, uint64_t* d_offsets, uint64_t n,
+                            const uint64_t* d_shard_totals, int rank, void* stream);
+
 /* ---- utilities used by the harness / benchmarks ---------------------------- */
+
+/* Kernel timing with HIP events on the launch stream: after hvlc_profile_begin every
+ * hvlc_encode brackets its k_encode launch (the dominant kernel) with an event pair, up
+ * to max_launches pairs.  hvlc_profile_collect synchronises those events, writes each
+ * launch's duration in milliseconds to ms[0..*count) and stops profiling. */
+int hvlc_profile_begin(hvlc_ctx* ctx, int max_launches);
+int hvlc_profile_collect(hvlc_ctx* ctx, float* ms, int* count);
 
 /* Deterministic synthetic symbol stream on the device:
  * r = splitmix64(seed + first_draw + j), two symbols per draw through a 256-entry
