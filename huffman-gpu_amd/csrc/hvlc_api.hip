@@ -113,7 +113,7 @@ int pick_blocks_per_cu(hvlc_ctx* c, K kernel, int cap)
     int b = occ > 1 ? occ - 1 : 1;
     if (b > cap) b = cap;
     const int forced = env_int("HVLC_BLOCKS_PER_CU", 0);
-    if (forced > 0) b = forced < occ ? forced : (occ > 1 ? occ - 1 : 1);
+    if (forced > 0) b = forced <= occ ? forced : occ;   // tuning override, never beyond what the API admits
     (void)c;
     return b;
 }

@@ -49,6 +49,7 @@ constexpr int      kTileVec     = kThreads * kRows;        // 1024 uint4
 constexpr int      kSegWords    = 256;
 constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 16
 constexpr int      kGroupTiles  = 64;
+constexpr uint32_t kFastBits    = 65536;                   // bits one staging buffer holds (2048 words)
 constexpr int      kStageWords  = 2064;                    // carry slot + 2048 (64 bit x 1024 lanes-rows) + pad, x2 buffers
 constexpr uint64_t kValid       = 1ull << 63;
 constexpr uint64_t kStAgg       = 1ull << 62;              // group granule: aggregate of the group
@@ -184,11 +185,18 @@ __device__ __forceinline__ uint32_t extract_tail(const uint32_t* st, uint32_t e)
 // acc is only meaningful while tot <= 64 (the reference's cw64 limit is per WORD,
 // vlc_kernel_sm64huff.cu:48,70; here it is per 16 symbols and checked, with a general path).
 // ---------------------------------------------------------------------------------------------
+//
+// The table sits in LDS at slot(s) = s ^ (s >> 4): symbol sets with a power-of-two stride (e.g. the
+// 16 symbols 16j+3 of BASELINE config 3) would otherwise hit two of the 32 ds_read_b64 bank pairs
+// and serialise 8-way.  hash4() applies the permutation to the four symbols of a word at once.
+__device__ __forceinline__ uint32_t lut_slot(uint32_t s) { return s ^ (s >> 4); }
+__device__ __forceinline__ uint32_t hash4(uint32_t w) { return w ^ ((w >> 4) & 0x0f0f0f0fu); }
+
 template <bool FULL>
 __device__ __forceinline__ void encode16(const uint4& v, int nvalid, const uint2* lut,
                                          uint64_t& acc, uint32_t& tot)
 {
-    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+    const uint32_t w[4] = { hash4(v.x), hash4(v.y), hash4(v.z), hash4(v.w) };
     acc = 0; tot = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -202,24 +210,70 @@ __device__ __forceinline__ void encode16(const uint4& v, int nvalid, const uint2
     }
 }
 
-struct alignas(16) Smem {
-    uint2    lut[256];                  // 2 KiB: {codeword, length}
-    uint32_t stage[2][kStageWords];     // double-buffered staging; [b][0] is the carry slot
-    uint32_t wave_tot[2][4];            // per-wave bit totals (bit 31: a lane-row exceeded 64 bits)
-    uint64_t prefix[2];                 // global exclusive bit offset of the tile
-    uint32_t pred_tail[2];              // last 31 bits of the stream before the tile
-    uint32_t qtot[4];                   // general path: per-wave totals of a quarter tile
-    uint32_t abort_flag;
+// A lane-row whose 16 codewords exceed 64 bits (lengths up to 31 allow 496): two symbols (<=62 bits)
+// per put_bits64.  Rare with real tables, so it runs as a divergent branch of the fast path.
+__device__ __forceinline__ void put_row_pairs(uint32_t* st, uint32_t q, const uint32_t (&wraw)[4], int nvalid,
+                                              const uint2* lut)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= nvalid) break;
+        const uint32_t w = hash4(wraw[k]);
+#pragma unroll
+        for (int b = 3; b >= 1; b -= 2) {
+            const uint2 e0 = lut[(w >> (8 * b)) & 255u];
+            const uint2 e1 = lut[(w >> (8 * (b - 1))) & 255u];
+            put_bits64(st, q, ((uint64_t)e0.x << e1.y) | e1.x, e0.y + e1.y);
+            q += e0.y + e1.y;
+        }
+    }
+}
+
+// Per-tile state that lives from the iteration that packs a tile to the iteration that stores it.
+struct TileState {
+    uint64_t prefix;        // global exclusive bit offset (look-back result)
+    uint32_t bits;          // T: bits of the tile
+    uint32_t pred_tail;     // last 31 bits of the stream before the tile
+    uint32_t flags;         // kTsEarlyTail | kTsPrefixReady
+    uint32_t seg_rel[kSegsPerTile];   // tile-local bit offset of each segment
 };
+enum : uint32_t { kTsEarlyTail = 1u, kTsPrefixReady = 2u };
+
+struct alignas(16) Smem {
+    uint2     lut[256];                 // 2 KiB: {codeword, length}
+    uint32_t  stage[2][kStageWords];    // double-buffered staging; [b][0] is the carry slot
+    uint32_t  wave_tot[2][4];           // per-wave bit totals (bit 31: a lane-row exceeded 64 bits)
+    TileState ts[2];
+    uint32_t  qtot[4];                  // general path: per-wave totals of a quarter tile
+    uint32_t  abort_flag;
+};
+
+// Granule values a look-back has in flight (wave 0 only).  Issued one iteration before they are
+// consumed, so the round trip to the other XCDs' writes overlaps the next tile's encode.
+struct LbRegs {
+    uint64_t d = 0;     // tile_bits of predecessor tile-1-lane (inside the group)
+    uint64_t v = 0;     // group_desc of group g-1-lane
+    uint64_t t = 0;     // tile_tail of tile-1 (lane 0)
+};
+
+__device__ __forceinline__ void lookback_issue(const EncodeParams& p, uint64_t tile, int lane, LbRegs& L)
+{
+    const uint32_t r = (uint32_t)(tile & (kGroupTiles - 1));
+    const int64_t  gi = (int64_t)(tile / kGroupTiles) - 1 - lane;
+    L.d = (uint32_t)lane < r ? ld_granule(p.tile_bits + (tile - 1 - (uint64_t)lane)) : 0ull;
+    L.v = gi >= 0 ? ld_granule(&p.group_desc[gi]) : 0ull;
+    L.t = (lane == 0 && tile > 0) ? ld_granule(&p.tile_tail[tile - 1]) : 0ull;
+}
 
 // Two-level decoupled look-back, executed by ONE wave with all 64 lanes active.
 // Level 1: lanes 0..r-1 read the bit counts of the r predecessors inside the tile's group.
 // Level 2: lanes read the granules of up to 64 preceding groups; the nearest inclusive prefix
 //          plus the aggregates after it give the group's exclusive prefix.  The last tile of a
-//          group publishes the group's aggregate as soon as level 1 is done and its inclusive
-//          prefix after level 2, so one hop covers 64 tiles / 64 groups.
+//          group (the "leader") publishes the group's aggregate as soon as level 1 is done and its
+//          inclusive prefix after level 2, so one hop covers 64 tiles / 64 groups.
+// `L` may carry values loaded earlier by lookback_issue (or zeros: everything is polled here).
 template <bool WIDE, bool TAIL>
-__device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, uint64_t T, int lane,
+__device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, uint64_t T, int lane, LbRegs L,
                                          uint64_t& P_out, uint32_t& pred_tail)
 {
     const uint32_t r = (uint32_t)(tile & (kGroupTiles - 1));
@@ -227,10 +281,11 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
     const bool leader = (r == kGroupTiles - 1) || (tile == p.num_tiles - 1);
     Spin spin;
 
-    uint64_t d = 0;
+    uint64_t d = L.d;
     const bool need = (uint32_t)lane < r;
     const uint64_t* src = p.tile_bits + (need ? tile - 1 - (uint64_t)lane : 0);
     for (;;) {
+        if (!__any(need && !(d >> 63))) break;
         if (need && !(d >> 63)) d = ld_granule(src);
         if (!__any(need && !(d >> 63))) break;
         if (!spin.wait(p)) return false;
@@ -241,17 +296,24 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
     if (leader && lane == 0) st_granule(&p.group_desc[g], kStAgg | ((insum + T) & kValMask));
 
     uint64_t excl = 0;
+    bool first = true;
     for (int64_t gb = (int64_t)g; gb > 0; gb -= 64) {
         const int64_t gi = gb - 1 - lane;
-        uint64_t v = gi < 0 ? kStPre : 0ull;          // before the stream: inclusive prefix 0
+        uint64_t v = gi < 0 ? kStPre : (first ? L.v : 0ull);   // before the stream: inclusive prefix 0
+        first = false;
         int fp;
         for (;;) {
-            if (gi >= 0 && (v >> 62) == 0) v = ld_granule(&p.group_desc[gi]);
             const uint64_t pm = __ballot((v >> 62) == 2);
             fp = pm ? __builtin_ctzll(pm) : 64;
             const uint64_t xm  = __ballot((v >> 62) == 0);
             const uint64_t low = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
             if ((xm & low) == 0) break;
+            if (gi >= 0 && (v >> 62) == 0) v = ld_granule(&p.group_desc[gi]);
+            const uint64_t pm2 = __ballot((v >> 62) == 2);
+            fp = pm2 ? __builtin_ctzll(pm2) : 64;
+            const uint64_t xm2  = __ballot((v >> 62) == 0);
+            const uint64_t low2 = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
+            if ((xm2 & low2) == 0) break;
             if (!spin.wait(p)) return false;
         }
         excl += wave_sum_u64(lane <= fp ? (v & kValMask) : 0ull);
@@ -262,8 +324,9 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
 
     uint32_t pt = 0;
     if (TAIL && tile > 0) {
-        uint64_t t = 0;
+        uint64_t t = L.t;
         for (;;) {
+            if (!__any(lane == 0 && !(t >> 63))) break;
             if (lane == 0 && !(t >> 63)) t = ld_granule(&p.tile_tail[tile - 1]);
             if (!__any(lane == 0 && !(t >> 63))) break;
             if (!spin.wait(p)) return false;
@@ -288,143 +351,101 @@ __device__ __forceinline__ void store_words(const EncodeParams& p, const uint32_
     }
 }
 
-// One tile.  Returns false (uniformly) if a wait timed out.
-template <bool FULL>
-__device__ __forceinline__ bool do_tile(const EncodeParams& p, Smem& sm, uint64_t tile, uint32_t par,
-                                        uint32_t& prev_used, int tid, int lane, int wave)
+__device__ __forceinline__ void zero_words(uint32_t* base, uint32_t n_vec4, int tid)
 {
-    const uint64_t word0 = tile * kTileWords;
-    const bool last = (tile == p.num_tiles - 1);
+    uint4* z = (uint4*)base;
+    for (uint32_t i = (uint32_t)tid; i < n_vec4; i += kThreads) z[i] = make_uint4(0, 0, 0, 0);
+}
 
-    // ---- (1) loads: lane-row r of wave w = segment 4w+r, 16 bytes per lane, 1 KiB per wave-instruction
-    uint4 raw[kRows];
-    int   nv[kRows];
+// Loads of one tile: lane-row r of wave w = segment 4w+r, 16 bytes per lane, 1 KiB per wave-instruction.
+__device__ __forceinline__ void load_tile(const EncodeParams& p, uint64_t tile, int wave, int lane, uint4 (&raw)[kRows])
+{
+    const bool full = (tile + 1) * (uint64_t)kTileWords <= p.num_words;
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
         const uint32_t vi = (uint32_t)((wave * kRows + r) * 64 + lane);     // uint4 index inside the tile
-        if (FULL) {
-            raw[r] = p.in[tile * kTileVec + vi];
-            nv[r]  = 4;
+        if (full) {
+            {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 t = __builtin_nontemporal_load((const u32x4*)&p.in[tile * kTileVec + vi]);
+                raw[r] = make_uint4(t.x, t.y, t.z, t.w);
+            }
         } else {
-            const uint64_t wbase = word0 + (uint64_t)vi * 4u;
+            const uint64_t wbase = tile * (uint64_t)kTileWords + (uint64_t)vi * 4u;
             const uint32_t* in32 = (const uint32_t*)p.in;
-            const int n = wbase >= p.num_words ? 0 : (p.num_words - wbase >= 4 ? 4 : (int)(p.num_words - wbase));
-            raw[r].x = n > 0 ? in32[wbase + 0] : 0u;
-            raw[r].y = n > 1 ? in32[wbase + 1] : 0u;
-            raw[r].z = n > 2 ? in32[wbase + 2] : 0u;
-            raw[r].w = n > 3 ? in32[wbase + 3] : 0u;
-            nv[r] = n;
+            raw[r].x = wbase + 0 < p.num_words ? in32[wbase + 0] : 0u;
+            raw[r].y = wbase + 1 < p.num_words ? in32[wbase + 1] : 0u;
+            raw[r].z = wbase + 2 < p.num_words ? in32[wbase + 2] : 0u;
+            raw[r].w = wbase + 3 < p.num_words ? in32[wbase + 3] : 0u;
         }
     }
+}
 
-    // ---- (2)+(3) lookups, concatenation, wave scans
-    uint64_t acc[kRows];
-    uint32_t tot[kRows], excl[kRows], rowbase[kRows];
-    uint32_t wavetot = 0;
-    bool over = false;
-#pragma unroll
-    for (int r = 0; r < kRows; ++r) {
-        encode16<FULL>(raw[r], nv[r], sm.lut, acc[r], tot[r]);
-        over |= tot[r] > 64u;
-        const uint32_t incl = wave_incl_scan(tot[r]);
-        excl[r]    = incl - tot[r];
-        rowbase[r] = wavetot;
-        wavetot   += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    }
-    const bool wave_over = __any(over);
-    if (lane == 0) sm.wave_tot[par][wave] = wavetot | (wave_over ? 0x80000000u : 0u);
-    __syncthreads();                                                          // B1
+__device__ __forceinline__ int valid_words(const EncodeParams& p, uint64_t wbase)
+{
+    return wbase >= p.num_words ? 0 : (p.num_words - wbase >= 4 ? 4 : (int)(p.num_words - wbase));
+}
 
-    const uint32_t t0 = sm.wave_tot[par][0], t1 = sm.wave_tot[par][1],
-                   t2 = sm.wave_tot[par][2], t3 = sm.wave_tot[par][3];
-    const bool slow = ((t0 | t1 | t2 | t3) >> 31) != 0u;
-    const uint32_t c0 = t0 & 0x7fffffffu, c1 = t1 & 0x7fffffffu, c2 = t2 & 0x7fffffffu, c3 = t3 & 0x7fffffffu;
-    const uint32_t T = c0 + c1 + c2 + c3;
-    const uint32_t wavebase = wave == 0 ? 0u : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
-
-    // ---- (4) publish the tile's bit count before anything else
-    if (tid == 0) st_granule(&p.tile_bits[tile], kValid | (uint64_t)T);
-
-    uint32_t* const sb = sm.stage[par];
-    uint32_t* const st = sb + 1;
-    const bool early_tail = !slow && c3 >= 31u;     // the tile's last 31 bits were all written by wave 3
-
-    // ---- (5) pack at tile-local bit positions
-    if (!slow) {
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) put_bits64(st, wavebase + rowbase[r] + excl[r], acc[r], tot[r]);
-        if (early_tail && wave == 3 && lane == 0)   // same-wave LDS ops complete in order
-            st_granule(&p.tile_tail[tile], kValid | (uint64_t)extract_tail(st, T));
-    }
-
-    // ---- (6) look-back
-    if (wave == 0) {
-        uint64_t P = 0; uint32_t pt = 0;
-        const bool ok = lookback<false, true>(p, tile, (uint64_t)T, lane, P, pt);
-        if (lane == 0) {
-            sm.prefix[par]    = P;
-            sm.pred_tail[par] = pt;
-            sb[0]             = pt;                 // carry slot of the staging buffer
-            if (!ok) sm.abort_flag = 1u;
-        }
-    }
-    __syncthreads();                                                          // B2
-    if (sm.abort_flag) return false;
-
-    const uint64_t P  = sm.prefix[par];
-    const uint32_t pt = sm.pred_tail[par];
-
-    if (p.offsets && lane == 0) {
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            const uint64_t seg = tile * kSegsPerTile + (uint64_t)(wave * kRows + r);
-            if (seg < p.num_segs) p.offsets[seg] = P + wavebase + rowbase[r];
-        }
+// Store the finished words of a packed tile (fast path) and everything that needs its global
+// offset: segment offsets, the total on the last tile, the tail granule when it could not be
+// published early.
+__device__ __forceinline__ void finish_tile(const EncodeParams& p, Smem& sm, uint64_t tile, uint32_t par, int tid)
+{
+    const TileState& ts = sm.ts[par];
+    const uint64_t P = ts.prefix;
+    const uint32_t T = ts.bits;
+    const bool last = (tile == p.num_tiles - 1);
+    const uint32_t* sb = sm.stage[par];
+    if (p.offsets && tid < kSegsPerTile) {
+        const uint64_t seg = tile * kSegsPerTile + (uint64_t)tid;
+        if (seg < p.num_segs) p.offsets[seg] = P + ts.seg_rel[tid];
     }
     if (last && tid == 0) {
         p.result[0] = P + T;
         if (p.total_bits) *p.total_bits = P + T;
     }
-
-    if (!slow) {
-        // ---- (7) funnel-shift + store the words this tile completes (the last tile also
-        //      stores the open word, zero padded, and the zero word cpu_vlc_encode leaves
-        //      behind when the stream ends on a word boundary, cpuencode.cpp:39)
-        const uint32_t s = (uint32_t)P & 31u;
-        uint32_t nown = (s + T) >> 5;
-        if (last) nown = ((s + T + 31u) >> 5) + ((((s + T) & 31u) == 0u) ? 1u : 0u);
-        store_words(p, sb, s, P >> 5, nown, tid);
-
-        if (!early_tail && tid == 0) {
-            const uint32_t own  = extract_tail(st, T);
-            const uint32_t tail = T >= 31u ? own : (((pt << T) | own) & 0x7fffffffu);
-            st_granule(&p.tile_tail[tile], kValid | (uint64_t)tail);
-        }
-        // zero the OTHER buffer (dirtied by the previous tile) for the next tile
-        uint4* z = (uint4*)sm.stage[par ^ 1u];
-        for (uint32_t i = (uint32_t)tid; i < prev_used; i += kThreads) z[i] = make_uint4(0, 0, 0, 0);
-        prev_used = (T >> 7) + 2u;                  // uint4s this tile dirtied: carry slot + T/32 words (+spill)
-        return true;
+    // the last tile also stores the open word, zero padded, and the zero word cpu_vlc_encode leaves
+    // behind when the stream ends on a word boundary (cpuencode.cpp:39)
+    const uint32_t s = (uint32_t)P & 31u;
+    uint32_t nown = (s + T) >> 5;
+    if (last) nown = ((s + T + 31u) >> 5) + ((((s + T) & 31u) == 0u) ? 1u : 0u);
+    store_words(p, sb, s, P >> 5, nown, tid);
+    if (!(ts.flags & kTsEarlyTail) && tid == 0) {
+        const uint32_t own  = extract_tail(sb + 1, T);
+        const uint32_t tail = T >= 31u ? own : (((ts.pred_tail << T) | own) & 0x7fffffffu);
+        st_granule(&p.tile_tail[tile], kValid | (uint64_t)tail);
     }
+}
 
-    // ------------------------------------------------------------------------------------------
-    // General path (some lane-row holds more than 64 bits; lengths up to 31 allow 496): the tile
-    // is re-read (L2) and packed quarter by quarter (4 KiB = wave-contiguous segments 4q..4q+3,
-    // at most 3968 words) into both staging buffers taken as one, two symbols (<=62 bits) per
-    // put_bits64.  The carry runs through the quarters exactly as it runs through tiles.
-    // ------------------------------------------------------------------------------------------
+// General path for one tile (some lane-row holds more than 64 bits; lengths up to 31 allow 496):
+// the tile is re-read (L2) and packed quarter by quarter (4 KiB = wave-contiguous segments 4q..4q+3,
+// at most 3968 words) into both staging buffers taken as one, two symbols (<=62 bits) per
+// put_bits64.  The carry runs through the quarters exactly as it runs through tiles.  Blocking:
+// the caller has no other tile in flight.  Leaves both staging buffers zeroed.
+__device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, uint64_t tile, uint32_t par, int tid,
+                                             int lane, int wave)
+{
+    const TileState& ts = sm.ts[par];
+    const bool last = (tile == p.num_tiles - 1);
+    const uint64_t word0 = tile * (uint64_t)kTileWords;
     uint32_t* const big = &sm.stage[0][0];
-    uint64_t Pq    = P;
-    uint32_t carry = pt;
+    uint64_t Pq    = ts.prefix;
+    uint32_t carry = ts.pred_tail;
+    const uint32_t T = ts.bits;
+    if (p.offsets && tid < kSegsPerTile) {
+        const uint64_t seg = tile * kSegsPerTile + (uint64_t)tid;
+        if (seg < p.num_segs) p.offsets[seg] = Pq + ts.seg_rel[tid];
+    }
+    if (last && tid == 0) {
+        p.result[0] = Pq + T;
+        if (p.total_bits) *p.total_bits = Pq + T;
+    }
     for (int qd = 0; qd < 4; ++qd) {
         __syncthreads();                            // previous quarter fully stored
-        {
-            uint4* z = (uint4*)big;
-            for (uint32_t i = (uint32_t)tid; i < 2u * kStageWords / 4u; i += kThreads) z[i] = make_uint4(0, 0, 0, 0);
-        }
+        zero_words(big, 2u * kStageWords / 4u, tid);
         const uint64_t wbase = word0 + (uint64_t)qd * 1024u + (uint64_t)tid * 4u;
         const uint32_t* in32 = (const uint32_t*)p.in;
-        const int n = wbase >= p.num_words ? 0 : (p.num_words - wbase >= 4 ? 4 : (int)(p.num_words - wbase));
+        const int n = valid_words(p, wbase);
         uint32_t w[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) w[k] = k < n ? in32[wbase + k] : 0u;
@@ -432,28 +453,18 @@ __device__ __forceinline__ bool do_tile(const EncodeParams& p, Smem& sm, uint64_
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (k < n) {
+                const uint32_t h = hash4(w[k]);
 #pragma unroll
-                for (int b = 3; b >= 0; --b) tq += sm.lut[(w[k] >> (8 * b)) & 255u].y;
+                for (int b = 3; b >= 0; --b) tq += sm.lut[(h >> (8 * b)) & 255u].y;
             }
         const uint32_t incl = wave_incl_scan(tq);
         if (lane == 63) sm.qtot[wave] = incl;
         __syncthreads();
         const uint32_t q0 = sm.qtot[0], q1 = sm.qtot[1], q2 = sm.qtot[2], q3 = sm.qtot[3];
         const uint32_t Tq = q0 + q1 + q2 + q3;
-        uint32_t pos = (incl - tq) + (wave == 0 ? 0u : wave == 1 ? q0 : wave == 2 ? q0 + q1 : q0 + q1 + q2);
+        const uint32_t pos = (incl - tq) + (wave == 0 ? 0u : wave == 1 ? q0 : wave == 2 ? q0 + q1 : q0 + q1 + q2);
         if (tid == 0) big[0] = carry;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < n) {
-#pragma unroll
-                for (int b = 3; b >= 1; b -= 2) {
-                    const uint2 e0 = sm.lut[(w[k] >> (8 * b)) & 255u];
-                    const uint2 e1 = sm.lut[(w[k] >> (8 * (b - 1))) & 255u];
-                    const uint64_t a = ((uint64_t)e0.x << e1.y) | e1.x;
-                    put_bits64(big + 1, pos, a, e0.y + e1.y);
-                    pos += e0.y + e1.y;
-                }
-            }
+        put_row_pairs(big + 1, pos, w, n, sm.lut);
         __syncthreads();
         const uint32_t s = (uint32_t)Pq & 31u;
         const bool lastq = last && qd == 3;
@@ -466,14 +477,21 @@ __device__ __forceinline__ bool do_tile(const EncodeParams& p, Smem& sm, uint64_
     }
     __syncthreads();
     if (tid == 0) st_granule(&p.tile_tail[tile], kValid | (uint64_t)carry);
-    {
-        uint4* z = (uint4*)big;
-        for (uint32_t i = (uint32_t)tid; i < 2u * kStageWords / 4u; i += kThreads) z[i] = make_uint4(0, 0, 0, 0);
-    }
-    prev_used = 0;
-    return true;
+    zero_words(big, 2u * kStageWords / 4u, tid);
 }
 
+// The persistent, software-pipelined encoder.  One loop iteration of a workgroup:
+//   phase X  issue the loads of its NEXT tile; look up / concatenate / scan the CURRENT tile
+//            (registers only); wave 0 resolves the PREVIOUS tile's global offset from the granules
+//            it requested one iteration ago; zero the staging buffer the current tile will use
+//   -- barrier 1 --
+//   phase Y  publish the current tile's bit count; store the previous tile (funnel shift from its
+//            staging buffer); pack the current tile into the other buffer; publish its tail;
+//            wave 0 requests the current tile's look-back granules (the last tile of a group
+//            resolves and publishes its group's prefix right away instead)
+//   -- barrier 2 --
+// so HBM latency, the granule round trip and the LDS bit packing of three different tiles overlap
+// inside one workgroup, on top of the overlap between the workgroups of a CU.
 __global__ void __launch_bounds__(kThreads) k_encode(EncodeParams p)
 {
     __shared__ Smem sm;
@@ -481,20 +499,154 @@ __global__ void __launch_bounds__(kThreads) k_encode(EncodeParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    sm.lut[tid] = p.lut[tid];
-    {
-        uint4* z = (uint4*)&sm.stage[0][0];
-        for (int i = tid; i < 2 * kStageWords / 4; i += kThreads) z[i] = make_uint4(0, 0, 0, 0);
-    }
-    if (tid == 0) sm.abort_flag = 0u;
+    sm.lut[lut_slot((uint32_t)tid)] = p.lut[tid];
+    zero_words(&sm.stage[0][0], 2u * kStageWords / 4u, tid);
+    if (tid == 0) { sm.abort_flag = 0u; sm.ts[0].bits = 0u; sm.ts[1].bits = 0u; }
+
+    uint64_t cur = blockIdx.x;
+    if (cur >= p.num_tiles) return;
+    const uint64_t stride = gridDim.x;
+    uint4 raw[kRows];
+    load_tile(p, cur, wave, lane, raw);
     __syncthreads();
 
-    uint32_t par = 0, prev_used = 0;
-    for (uint64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x, par ^= 1u) {
-        const bool full = (tile + 1) * (uint64_t)kTileWords <= p.num_words;
-        const bool ok = full ? do_tile<true>(p, sm, tile, par, prev_used, tid, lane, wave)
-                             : do_tile<false>(p, sm, tile, par, prev_used, tid, lane, wave);
-        if (!ok) return;
+    bool     has_prev = false;
+    uint64_t prev = 0;
+    uint32_t par = 0;                    // staging buffer / TileState slot of `cur`
+    LbRegs   lb;                         // wave 0: granules requested for `prev`
+
+    for (;;) {
+        const uint64_t nxt = cur + stride;
+        const bool has_nxt = nxt < p.num_tiles;
+        const bool full = (cur + 1) * (uint64_t)kTileWords <= p.num_words;
+
+        // ---------------- phase X ----------------
+        uint64_t acc[kRows];
+        uint32_t tot[kRows], excl[kRows], rowbase[kRows];
+        uint32_t wavetot = 0;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            if (full) {
+                encode16<true>(raw[r], 4, sm.lut, acc[r], tot[r]);
+            } else {
+                const uint64_t wbase = cur * (uint64_t)kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
+                encode16<false>(raw[r], valid_words(p, wbase), sm.lut, acc[r], tot[r]);
+            }
+            const uint32_t incl = wave_incl_scan(tot[r]);
+            excl[r]    = incl - tot[r];
+            rowbase[r] = wavetot;
+            wavetot   += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0) sm.wave_tot[par][wave] = wavetot;
+        if (has_nxt) load_tile(p, nxt, wave, lane, raw);      // raw is dead: its registers take the next tile
+
+        if (has_prev && wave == 0 && !(sm.ts[par ^ 1u].flags & kTsPrefixReady)) {
+            uint64_t P = 0; uint32_t pt = 0;
+            const bool ok = lookback<false, true>(p, prev, (uint64_t)sm.ts[par ^ 1u].bits, lane, lb, P, pt);
+            if (lane == 0) {
+                sm.ts[par ^ 1u].prefix    = P;
+                sm.ts[par ^ 1u].pred_tail = pt;
+                sm.stage[par ^ 1u][0]     = pt;           // carry slot of prev's staging buffer
+                if (!ok) sm.abort_flag = 1u;
+            }
+        }
+        // the buffer `cur` will be packed into was last used two tiles ago (stored one iteration ago)
+        zero_words(sm.stage[par], (sm.ts[par].bits >> 7) + 2u, tid);
+        __syncthreads();                                                      // barrier 1
+        if (sm.abort_flag) return;
+
+        // ---------------- phase Y ----------------
+        const uint32_t c0 = sm.wave_tot[par][0], c1 = sm.wave_tot[par][1],
+                       c2 = sm.wave_tot[par][2], c3 = sm.wave_tot[par][3];
+        const uint32_t T = c0 + c1 + c2 + c3;
+        const bool slow = T > kFastBits;                 // does not fit one staging buffer: general path
+        const uint32_t wavebase = wave == 0 ? 0u : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+        const bool early_tail = !slow && c3 >= 31u;     // the tile's last 31 bits are all written by wave 3
+        const uint32_t rtile = (uint32_t)(cur & (kGroupTiles - 1));
+        const bool leader = (rtile == kGroupTiles - 1) || (cur == p.num_tiles - 1);
+
+        if (tid == 0) {
+            st_granule(&p.tile_bits[cur], kValid | (uint64_t)T);   // publish before anything else
+            sm.ts[par].bits  = T;
+            sm.ts[par].flags = early_tail ? kTsEarlyTail : 0u;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) sm.ts[par].seg_rel[wave * kRows + r] = wavebase + rowbase[r];
+        }
+
+        if (has_prev) finish_tile(p, sm, prev, par ^ 1u, tid);
+
+        if (!slow) {
+            uint32_t* const st = sm.stage[par] + 1;
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                const uint32_t q = wavebase + rowbase[r] + excl[r];
+                if (tot[r] <= 64u) {
+                    put_bits64(st, q, acc[r], tot[r]);
+                } else {                                   // rare: re-read this lane's 16 bytes (L2) and go pairwise
+                    const uint64_t wbase = cur * (uint64_t)kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
+                    const uint32_t* in32 = (const uint32_t*)p.in;
+                    const int n = valid_words(p, wbase);
+                    uint32_t w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w[k] = k < n ? in32[wbase + k] : 0u;
+                    put_row_pairs(st, q, w, n, sm.lut);
+                }
+            }
+            if (early_tail && wave == 3 && lane == 0)   // same-wave LDS ops complete in order
+                st_granule(&p.tile_tail[cur], kValid | (uint64_t)extract_tail(st, T));
+        }
+
+        if (wave == 0) {
+            if (leader || slow) {
+                // resolve now: a group leader publishes its group's aggregate / prefix without waiting an
+                // iteration; the general path needs its offset before it can store anything
+                uint64_t P = 0; uint32_t pt = 0;
+                const bool ok = lookback<false, true>(p, cur, (uint64_t)T, lane, LbRegs(), P, pt);
+                if (lane == 0) {
+                    sm.ts[par].prefix    = P;
+                    sm.ts[par].pred_tail = pt;
+                    sm.ts[par].flags    |= kTsPrefixReady;
+                    sm.stage[par][0]     = pt;
+                    if (!ok) sm.abort_flag = 1u;
+                }
+            } else {
+                lookback_issue(p, cur, lane, lb);
+            }
+        }
+        __syncthreads();                                                      // barrier 2
+        if (sm.abort_flag) return;
+
+        if (slow) {
+            general_tile(p, sm, cur, par, tid, lane, wave);
+            if (tid == 0) { sm.ts[0].bits = 0u; sm.ts[1].bits = 0u; }   // both buffers are clean again
+            has_prev = false;
+        } else {
+            has_prev = true;
+            prev = cur;
+        }
+        if (!has_nxt) break;
+        cur = nxt;
+        par ^= 1u;
+        if (slow) __syncthreads();       // general_tile's final zeroing / ts reset before the next phase X
+    }
+
+    if (has_prev) {                      // drain: the last packed tile of this workgroup
+        const uint32_t pp = par;         // `par` was not flipped after the final iteration
+        if (wave == 0 && !(sm.ts[pp].flags & kTsPrefixReady)) {
+            uint64_t P = 0; uint32_t pt = 0;
+            const bool ok = lookback<false, true>(p, prev, (uint64_t)sm.ts[pp].bits, lane, lb, P, pt);
+            if (lane == 0) {
+                sm.ts[pp].prefix    = P;
+                sm.ts[pp].pred_tail = pt;
+                sm.stage[pp][0]     = pt;
+                if (!ok) sm.abort_flag = 1u;
+            }
+        }
+        __syncthreads();
+        if (sm.abort_flag) return;
+        finish_tile(p, sm, prev, pp, tid);
     }
 }
 
@@ -593,7 +745,7 @@ __global__ void __launch_bounds__(kThreads) k_exclusive_scan(const uint32_t* in,
         if (tid == 0) st_granule(&p.tile_bits[tile], kValid | (T & kValMask));
         if (wave == 0) {
             uint64_t P = 0; uint32_t unused = 0;
-            const bool ok = lookback<true, false>(p, tile, T, lane, P, unused);
+            const bool ok = lookback<true, false>(p, tile, T, lane, LbRegs(), P, unused);
             if (lane == 0) { s_prefix = P; if (!ok) s_abort = 1u; }
         }
         __syncthreads();
