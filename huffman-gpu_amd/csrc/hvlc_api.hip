@@ -106,10 +106,10 @@ int env_int(const char* name, int dflt)
 // occupancy API can over-report by one block per CU for SGPR-heavy 256-thread kernels on
 // ROCm 7.2 (CDNA4 guide), so one block per CU is given back as margin.
 template <typename K>
-int pick_blocks_per_cu(hvlc_ctx* c, K kernel, int cap)
+int pick_blocks_per_cu(hvlc_ctx* c, K kernel, int block_threads, int cap)
 {
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kThreads, 0) != hipSuccess || occ < 1) occ = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block_threads, 0) != hipSuccess || occ < 1) occ = 2;
     int b = occ > 1 ? occ - 1 : 1;
     if (b > cap) b = cap;
     const int forced = env_int("HVLC_BLOCKS_PER_CU", 0);
@@ -118,6 +118,10 @@ int pick_blocks_per_cu(hvlc_ctx* c, K kernel, int cap)
     return b;
 }
 
+#ifdef HVLC_EXPERIMENT
+uint64_t* g_dbg_buf = nullptr;     // tools/ only: phase stamps
+uint64_t* g_dbg_tl = nullptr;      // tools/ only: per-tile timeline
+#endif
 std::mutex g_default_mu;
 hvlc_ctx*  g_default_ctx = nullptr;
 
@@ -169,7 +173,7 @@ int hvlc_create(hvlc_ctx** out, int device, uint64_t max_words)
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) { delete c; return HVLC_ERR_HIP; }
     c->cus = prop.multiProcessorCount;
-    c->blocks_per_cu = pick_blocks_per_cu(c, k_encode, env_int("HVLC_MAX_BLOCKS_PER_CU", 8));
+    c->blocks_per_cu = pick_blocks_per_cu(c, k_encode, kEncThreads, env_int("HVLC_MAX_BLOCKS_PER_CU", 8));
     const int to_ms = env_int("HVLC_TIMEOUT_MS", 2000);
     c->timeout_ticks = (uint64_t)(to_ms > 0 ? to_ms : 2000) * 100000ull;
     int rc = ensure_workspace(c, (max_words + kTileWords - 1) / kTileWords);
@@ -224,11 +228,18 @@ int hvlc_encode(hvlc_ctx* c,
 
     EncodeParams p;
     memset(&p, 0, sizeof(p));
+    if (tiles > 0xfffffff0ull) return HVLC_ERR_ARG;          // 32-bit tile numbers: 64 TiB per call
     p.in = (const uint4*)d_in;  p.num_words = num_words;  p.num_tiles = tiles;
+    p.num_full_tiles = (uint32_t)(num_words / kTileWords);
     p.num_segs = hvlc_num_segments(num_words);
     p.lut = ws_lut(c);  p.out = d_out_bits;  p.out_cap = out_capacity_words;
     p.offsets = d_out_offsets;  p.total_bits = d_total_bits;
     fill_granule_ptrs(c, tiles, p);
+#ifdef HVLC_EXPERIMENT
+    p.dbg = (uint32_t)env_int("HVLC_DBG", 0);
+    p.dbg_buf = g_dbg_buf;
+    p.dbg_tl = g_dbg_tl;
+#endif
 
     const Layout l = layout_for(tiles);
     const uint64_t vecs = l.bytes / 16;
@@ -247,11 +258,16 @@ int hvlc_encode(hvlc_ctx* c,
     c->last_grid = (int)grid;
     const bool prof = c->ev && c->ev_used < c->ev_cap;
     if (prof) HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used], s));
-    hipLaunchKernelGGL(k_encode, dim3((unsigned)grid), dim3(kThreads), 0, s, p);
+    hipLaunchKernelGGL(k_encode, dim3((unsigned)grid), dim3(kEncThreads), 0, s, p);
     HVLC_HIP(c, hipGetLastError());
     if (prof) { HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used + 1], s)); c->ev_used++; }
     return HVLC_OK;
 }
+
+#ifdef HVLC_EXPERIMENT
+int hvlc_debug_set_buffer(void* d_buf) { g_dbg_buf = (uint64_t*)d_buf; return 0; }
+int hvlc_debug_set_timeline(void* d_buf) { g_dbg_tl = (uint64_t*)d_buf; return 0; }
+#endif
 
 int hvlc_profile_begin(hvlc_ctx* c, int max_launches)
 {
@@ -379,7 +395,7 @@ int hvlc_exclusive_scan(hvlc_ctx* c, const uint32_t* d_counts, uint64_t n,
     HVLC_HIP(c, hipMemsetAsync(ws_gran(c), 0, l.bytes, s));
     HVLC_HIP(c, hipMemsetAsync(ws_status(c), 0, 16, s));
     static int scan_bpc = 0;
-    if (!scan_bpc) scan_bpc = pick_blocks_per_cu(c, k_exclusive_scan, 4);
+    if (!scan_bpc) scan_bpc = pick_blocks_per_cu(c, k_exclusive_scan, kThreads, 4);
     uint64_t grid = (uint64_t)c->cus * (uint64_t)scan_bpc;
     if (grid > tiles) grid = tiles;
     hipLaunchKernelGGL(k_exclusive_scan, dim3((unsigned)grid), dim3(kThreads), 0, s, d_counts, n, d_offsets, d_total, p);

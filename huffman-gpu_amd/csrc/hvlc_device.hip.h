@@ -42,7 +42,8 @@
 
 namespace hvlc {
 
-constexpr int      kThreads     = 256;
+constexpr int      kThreads     = 256;                     // data threads of the encoder (4 waves) / block size of the small kernels
+constexpr int      kEncThreads  = 320;                     // k_encode: 4 data waves + 1 scout wave
 constexpr int      kRows        = 4;                       // 16-byte rows per lane per tile
 constexpr int      kTileWords   = kThreads * kRows * 4;    // 4096 words = 16 KiB
 constexpr int      kTileVec     = kThreads * kRows;        // 1024 uint4
@@ -50,7 +51,9 @@ constexpr int      kSegWords    = 256;
 constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 16
 constexpr int      kGroupTiles  = 64;
 constexpr uint32_t kFastBits    = 65536;                   // bits one staging buffer holds (2048 words)
-constexpr int      kStageWords  = 2064;                    // carry slot + 2048 (64 bit x 1024 lanes-rows) + pad, x2 buffers
+constexpr int      kStageWords  = 2064;                    // carry slot + 2048 (64 bit x 1024 lane-rows) + pad
+constexpr int      kSlots       = 4;                       // staging slots (packed tiles in flight) per workgroup
+constexpr uint32_t kPollAge     = 1;                       // a tile's granules are requested once this many newer tiles are packed
 constexpr uint64_t kValid       = 1ull << 63;
 constexpr uint64_t kStAgg       = 1ull << 62;              // group granule: aggregate of the group
 constexpr uint64_t kStPre       = 2ull << 62;              // group granule: inclusive prefix through the group
@@ -62,6 +65,7 @@ struct EncodeParams {
     const uint4*    in;          // input words, 16-byte aligned
     uint64_t        num_words;
     uint64_t        num_tiles;
+    uint32_t        num_full_tiles;  // tiles that lie completely inside the input (num_words / 4096)
     uint64_t        num_segs;
     const uint2*    lut;         // {codeword (masked), length} x 256, built by k_prepare
     uint32_t*       out;         // final stream
@@ -74,7 +78,40 @@ struct EncodeParams {
     uint64_t*       tile_tail;   // granule per tile: kValid | last 31 bits of the stream through this tile
     uint64_t*       group_desc;  // granule per group: status | value
     uint64_t        timeout_ticks;   // s_memrealtime ticks (100 MHz)
+    uint32_t        dbg;             // ablation flags, honoured only in -DHVLC_EXPERIMENT builds (tools/)
+    uint64_t*       dbg_buf;         // phase stamps [grid][2][16], -DHVLC_EXPERIMENT builds only
+    uint64_t*       dbg_tl;          // per-tile timeline [tiles][8] (100 MHz ticks), -DHVLC_EXPERIMENT builds only
 };
+
+// Ablation switches for tools/ablate.py.  In the product build HVLC_DBG() is a compile-time false.
+enum : uint32_t { kDbgNoLookback = 1u, kDbgNoStore = 2u, kDbgNoPack = 4u, kDbgNoLookup = 8u, kDbgNoOffsets = 16u };
+#ifdef HVLC_EXPERIMENT
+#define HVLC_DBG(p, bit) (((p).dbg & (bit)) != 0u)
+// diagnostic phase timer (never in the product build): accumulates s_memtime deltas per phase
+struct Stamps {
+    uint64_t last, acc[16];
+    __device__ __forceinline__ void init() { for (int i = 0; i < 16; ++i) acc[i] = 0; last = clock64(); }
+    __device__ __forceinline__ void lap(int i) { const uint64_t t = clock64(); acc[i] += t - last; last = t; }
+    __device__ __forceinline__ void count(int i, uint64_t v = 1) { acc[i] += v; }
+    __device__ __forceinline__ void dump(uint64_t* buf, int which) {
+        if (buf) for (int i = 0; i < 16; ++i) buf[((uint64_t)blockIdx.x * 2 + which) * 16 + i] = acc[i];
+    }
+};
+#define STAMP_DECL Stamps stamps; stamps.init()
+#define STAMP(i) stamps.lap(i)
+#define STAMP_COUNT(i, v) stamps.count(i, v)
+#define STAMP_DUMP(buf, which, cond) do { if (cond) stamps.dump(buf, which); } while (0)
+#define TL(p, tile, k, cond) do { if ((p).dbg_tl && (cond)) (p).dbg_tl[(uint64_t)(tile) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TLV(p, tile, k, v, cond) do { if ((p).dbg_tl && (cond)) (p).dbg_tl[(uint64_t)(tile) * 8 + (k)] = (v); } while (0)
+#else
+#define TL(p, tile, k, cond)
+#define TLV(p, tile, k, v, cond)
+#define HVLC_DBG(p, bit) false
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_COUNT(i, v)
+#define STAMP_DUMP(buf, which, cond)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
@@ -240,12 +277,30 @@ struct TileState {
 enum : uint32_t { kTsEarlyTail = 1u, kTsPrefixReady = 2u };
 
 struct alignas(16) Smem {
-    uint2     lut[256];                 // 2 KiB: {codeword, length}
-    uint32_t  stage[2][kStageWords];    // double-buffered staging; [b][0] is the carry slot
-    uint32_t  wave_tot[2][4];           // per-wave bit totals (bit 31: a lane-row exceeded 64 bits)
-    TileState ts[2];
-    uint32_t  qtot[4];                  // general path: per-wave totals of a quarter tile
+    uint2     lut[256];                     // 2 KiB: {codeword, length}
+    uint32_t  stage[kSlots][kStageWords];   // ring of staging slots; [s][0] is the carry slot
+    uint32_t  wave_tot[4];                  // per-wave bit totals of the tile being packed
+    TileState ts[kSlots];
+    uint32_t  qtot[4];                      // general path: per-wave totals of a quarter tile
+    uint32_t  n_resolved;                   // scout -> data: tiles whose global offset is known (in order)
+    uint32_t  n_packed_pub;                 // data -> scout: tiles whose bit count / ts[] entry is published
+    uint32_t  n_res_snap;                   // data waves: per-iteration snapshot of n_resolved (uniform decisions)
+    uint32_t  bar;                          // arrival counter of the data waves' LDS barrier
     uint32_t  abort_flag;
+};
+
+// Barrier among the 4 DATA waves only, through an LDS counter: the scout wave never takes part, so a
+// granule round trip it is waiting for can never stall the data path (s_barrier would include it).
+// LDS operations of one wave complete in order, so a wave that sees all 4 arrivals also sees
+// everything the others wrote to LDS before arriving.
+struct DataBarrier {
+    uint32_t target = 0;
+    __device__ __forceinline__ void sync(Smem& sm, int lane)
+    {
+        target += 4u;
+        if (lane == 0) (void)__hip_atomic_fetch_add(&sm.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&sm.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) { }
+    }
 };
 
 // Granule values a look-back has in flight (wave 0 only).  Issued one iteration before they are
@@ -260,6 +315,7 @@ __device__ __forceinline__ void lookback_issue(const EncodeParams& p, uint64_t t
 {
     const uint32_t r = (uint32_t)(tile & (kGroupTiles - 1));
     const int64_t  gi = (int64_t)(tile / kGroupTiles) - 1 - lane;
+    if (HVLC_DBG(p, kDbgNoLookback)) return;
     L.d = (uint32_t)lane < r ? ld_granule(p.tile_bits + (tile - 1 - (uint64_t)lane)) : 0ull;
     L.v = gi >= 0 ? ld_granule(&p.group_desc[gi]) : 0ull;
     L.t = (lane == 0 && tile > 0) ? ld_granule(&p.tile_tail[tile - 1]) : 0ull;
@@ -280,6 +336,7 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
     const uint64_t g = tile / kGroupTiles;
     const bool leader = (r == kGroupTiles - 1) || (tile == p.num_tiles - 1);
     Spin spin;
+    if (HVLC_DBG(p, kDbgNoLookback)) { P_out = tile * 36400ull; pred_tail = 0; return true; }
 
     uint64_t d = L.d;
     const bool need = (uint32_t)lane < r;
@@ -338,6 +395,94 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
     return true;
 }
 
+// One look-back in progress in the scout wave.  step() is NON-BLOCKING unless told otherwise: it
+// evaluates the granules requested earlier, re-requests exactly those still missing and returns 0,
+// to be called again half an iteration later; 1 = resolved (P / pred_tail valid), -1 = timed out.
+// A group leader (last tile of its group) publishes the group's aggregate as soon as its in-group
+// predecessors are known and the group's inclusive prefix as soon as the group window is resolved:
+// both are on every later tile's critical path.
+struct Resolver {
+    LbRegs   L;
+    uint64_t insum = 0;
+    uint32_t n = 0;             // workgroup-local tile number
+    bool     active = false;
+    bool     ga_done = false;
+
+    __device__ __forceinline__ void start(const EncodeParams& p, uint32_t n_, uint64_t tile, int lane)
+    {
+        n = n_; active = true; ga_done = false; insum = 0;
+        lookback_issue(p, tile, lane, L);
+    }
+
+    uint32_t why = 0;           // diagnostics (experiment build): which granules the last step() was missing
+
+    __device__ __forceinline__ int step(const EncodeParams& p, uint64_t tile, uint32_t T, int lane, bool block,
+                                        uint64_t& P_out, uint32_t& pred_tail)
+    {
+        if (HVLC_DBG(p, kDbgNoLookback)) { P_out = tile * 36400ull; pred_tail = 0; active = false; return 1; }
+        const uint32_t r = (uint32_t)(tile & (kGroupTiles - 1));
+        const uint64_t g = tile / kGroupTiles;
+        const bool leader = (r == kGroupTiles - 1) || (tile == p.num_tiles - 1);
+        const bool need = (uint32_t)lane < r;
+        const bool need_t = (lane == 0 && tile > 0);
+        const int64_t gi = (int64_t)g - 1 - lane;
+        Spin spin;
+        int fp;
+        uint64_t v;
+        for (;;) {
+            v = gi < 0 ? kStPre : L.v;                              // before the stream: inclusive prefix 0
+            const uint64_t pm  = __ballot((v >> 62) == 2);
+            fp = pm ? __builtin_ctzll(pm) : 64;
+            const uint64_t xm  = __ballot((v >> 62) == 0);
+            const uint64_t low = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
+            const bool miss_d = need && !(L.d >> 63);
+            const bool miss_v = ((xm & low) >> lane) & 1ull;
+            const bool miss_t = need_t && !(L.t >> 63);
+            if (!ga_done && !__any(miss_d)) {
+                insum = (uint64_t)wave_sum_u32(need ? (uint32_t)L.d : 0u);
+                if (leader && lane == 0) st_granule(&p.group_desc[g], kStAgg | (insum + T));
+                TL(p, tile, 3, leader && lane == 0);
+                TL(p, tile, 2, !leader && lane == 0);
+                ga_done = true;
+            }
+            if (!__any(miss_d || miss_v || miss_t)) break;
+#ifdef HVLC_EXPERIMENT
+            why = (__any(miss_d) ? 1u : 0u) | (__any(miss_v) ? 2u : 0u) | (__any(miss_t) ? 4u : 0u);
+#endif
+            if (miss_d) L.d = ld_granule(p.tile_bits + (tile - 1 - (uint64_t)lane));
+            if (miss_v) L.v = ld_granule(&p.group_desc[gi]);
+            if (miss_t) L.t = ld_granule(&p.tile_tail[tile - 1]);
+            if (!block) return 0;
+            if (!spin.wait(p)) return -1;
+        }
+        uint64_t excl = wave_sum_u64(lane <= fp ? (v & kValMask) : 0ull);
+        if (fp == 64) {                                             // no prefix in the nearest 64 groups (rare): keep going
+            for (int64_t gb = (int64_t)g - 64; gb > 0; gb -= 64) {
+                const int64_t gj = gb - 1 - lane;
+                uint64_t u = gj < 0 ? kStPre : 0ull;
+                int fq;
+                for (;;) {
+                    if (gj >= 0 && (u >> 62) == 0) u = ld_granule(&p.group_desc[gj]);
+                    const uint64_t pm  = __ballot((u >> 62) == 2);
+                    fq = pm ? __builtin_ctzll(pm) : 64;
+                    const uint64_t xm  = __ballot((u >> 62) == 0);
+                    const uint64_t low = fq >= 63 ? ~0ull : ((2ull << fq) - 1ull);
+                    if ((xm & low) == 0) break;
+                    if (!spin.wait(p)) return -1;
+                }
+                excl += wave_sum_u64(lane <= fq ? (u & kValMask) : 0ull);
+                if (fq < 64) break;
+            }
+        }
+        const uint64_t P = excl + insum;
+        if (leader && lane == 0) st_granule(&p.group_desc[g], kStPre | (P + T));
+        P_out = P;
+        pred_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.t) & 0x7fffffffu;
+        active = false;
+        return 1;
+    }
+};
+
 // Funnel-shift the staging buffer by s = (global bit offset % 32) and store `nown` finished words
 // at out[ow..].  sb[0] is the carry slot (low s bits = last s bits of the preceding stream).
 __device__ __forceinline__ void store_words(const EncodeParams& p, const uint32_t* sb, uint32_t s,
@@ -346,6 +491,7 @@ __device__ __forceinline__ void store_words(const EncodeParams& p, const uint32_
     for (uint32_t k = (uint32_t)tid; k < nown; k += kThreads) {
         const uint32_t v = __builtin_amdgcn_alignbit(sb[k], sb[k + 1], s);
         const uint64_t idx = ow + k;
+        if (HVLC_DBG(p, kDbgNoStore)) { if (v == 0x12345u) p.out[0] = v; continue; }
         if (idx < p.out_cap) p.out[idx] = v;
         else atomicOr(p.status, kFlagCapacity);
     }
@@ -357,22 +503,25 @@ __device__ __forceinline__ void zero_words(uint32_t* base, uint32_t n_vec4, int 
     for (uint32_t i = (uint32_t)tid; i < n_vec4; i += kThreads) z[i] = make_uint4(0, 0, 0, 0);
 }
 
-// Loads of one tile: lane-row r of wave w = segment 4w+r, 16 bytes per lane, 1 KiB per wave-instruction.
-__device__ __forceinline__ void load_tile(const EncodeParams& p, uint64_t tile, int wave, int lane, uint4 (&raw)[kRows])
+// Loads of one tile: lane-row r of wave w = segment 4w+r, 16 bytes per lane, 1 KiB per wave-instruction,
+// non-temporal (the input is read exactly once).  `full` must be wave-uniform (a scalar branch): the
+// four loads of a full tile are issued back to back with nothing between them.
+__device__ __forceinline__ void load_tile(const EncodeParams& p, uint32_t tile, bool full, int wave, int lane,
+                                          uint4 (&raw)[kRows])
 {
-    const bool full = (tile + 1) * (uint64_t)kTileWords <= p.num_words;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if (full) {
+        const u32x4* src = (const u32x4*)p.in + ((uint64_t)tile * kTileVec + (uint32_t)(wave * kRows * 64 + lane));
 #pragma unroll
-    for (int r = 0; r < kRows; ++r) {
-        const uint32_t vi = (uint32_t)((wave * kRows + r) * 64 + lane);     // uint4 index inside the tile
-        if (full) {
-            {
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 t = __builtin_nontemporal_load((const u32x4*)&p.in[tile * kTileVec + vi]);
-                raw[r] = make_uint4(t.x, t.y, t.z, t.w);
-            }
-        } else {
-            const uint64_t wbase = tile * (uint64_t)kTileWords + (uint64_t)vi * 4u;
-            const uint32_t* in32 = (const uint32_t*)p.in;
+        for (int r = 0; r < kRows; ++r) {
+            const u32x4 t = __builtin_nontemporal_load(src + r * 64);
+            raw[r] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+    } else {
+        const uint32_t* in32 = (const uint32_t*)p.in;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const uint64_t wbase = (uint64_t)tile * kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
             raw[r].x = wbase + 0 < p.num_words ? in32[wbase + 0] : 0u;
             raw[r].y = wbase + 1 < p.num_words ? in32[wbase + 1] : 0u;
             raw[r].z = wbase + 2 < p.num_words ? in32[wbase + 2] : 0u;
@@ -396,7 +545,7 @@ __device__ __forceinline__ void finish_tile(const EncodeParams& p, Smem& sm, uin
     const uint32_t T = ts.bits;
     const bool last = (tile == p.num_tiles - 1);
     const uint32_t* sb = sm.stage[par];
-    if (p.offsets && tid < kSegsPerTile) {
+    if (p.offsets && tid < kSegsPerTile && !HVLC_DBG(p, kDbgNoOffsets)) {
         const uint64_t seg = tile * kSegsPerTile + (uint64_t)tid;
         if (seg < p.num_segs) p.offsets[seg] = P + ts.seg_rel[tid];
     }
@@ -422,8 +571,8 @@ __device__ __forceinline__ void finish_tile(const EncodeParams& p, Smem& sm, uin
 // at most 3968 words) into both staging buffers taken as one, two symbols (<=62 bits) per
 // put_bits64.  The carry runs through the quarters exactly as it runs through tiles.  Blocking:
 // the caller has no other tile in flight.  Leaves both staging buffers zeroed.
-__device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, uint64_t tile, uint32_t par, int tid,
-                                             int lane, int wave)
+__device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, DataBarrier& bar, uint64_t tile,
+                                             uint32_t par, int tid, int lane, int wave)
 {
     const TileState& ts = sm.ts[par];
     const bool last = (tile == p.num_tiles - 1);
@@ -441,7 +590,7 @@ __device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, ui
         if (p.total_bits) *p.total_bits = Pq + T;
     }
     for (int qd = 0; qd < 4; ++qd) {
-        __syncthreads();                            // previous quarter fully stored
+        bar.sync(sm, lane);                            // previous quarter fully stored
         zero_words(big, 2u * kStageWords / 4u, tid);
         const uint64_t wbase = word0 + (uint64_t)qd * 1024u + (uint64_t)tid * 4u;
         const uint32_t* in32 = (const uint32_t*)p.in;
@@ -459,13 +608,13 @@ __device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, ui
             }
         const uint32_t incl = wave_incl_scan(tq);
         if (lane == 63) sm.qtot[wave] = incl;
-        __syncthreads();
+        bar.sync(sm, lane);
         const uint32_t q0 = sm.qtot[0], q1 = sm.qtot[1], q2 = sm.qtot[2], q3 = sm.qtot[3];
         const uint32_t Tq = q0 + q1 + q2 + q3;
         const uint32_t pos = (incl - tq) + (wave == 0 ? 0u : wave == 1 ? q0 : wave == 2 ? q0 + q1 : q0 + q1 + q2);
         if (tid == 0) big[0] = carry;
         put_row_pairs(big + 1, pos, w, n, sm.lut);
-        __syncthreads();
+        bar.sync(sm, lane);
         const uint32_t s = (uint32_t)Pq & 31u;
         const bool lastq = last && qd == 3;
         uint32_t nown = (s + Tq) >> 5;
@@ -475,179 +624,278 @@ __device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, ui
         carry = Tq >= 31u ? own : (((carry << Tq) | own) & 0x7fffffffu);
         Pq += Tq;
     }
-    __syncthreads();
+    bar.sync(sm, lane);
     if (tid == 0) st_granule(&p.tile_tail[tile], kValid | (uint64_t)carry);
     zero_words(big, 2u * kStageWords / 4u, tid);
 }
 
-// The persistent, software-pipelined encoder.  One loop iteration of a workgroup:
-//   phase X  issue the loads of its NEXT tile; look up / concatenate / scan the CURRENT tile
-//            (registers only); wave 0 resolves the PREVIOUS tile's global offset from the granules
-//            it requested one iteration ago; zero the staging buffer the current tile will use
-//   -- barrier 1 --
-//   phase Y  publish the current tile's bit count; store the previous tile (funnel shift from its
-//            staging buffer); pack the current tile into the other buffer; publish its tail;
-//            wave 0 requests the current tile's look-back granules (the last tile of a group
-//            resolves and publishes its group's prefix right away instead)
-//   -- barrier 2 --
-// so HBM latency, the granule round trip and the LDS bit packing of three different tiles overlap
-// inside one workgroup, on top of the overlap between the workgroups of a CU.
-__global__ void __launch_bounds__(kThreads) k_encode(EncodeParams p)
+// Workgroup-uniform control state of the data waves' ring pipeline.
+struct RingCtl {
+    uint32_t n_packed = 0, n_stored = 0, n_res = 0;   // tiles packed / stored / resolved (workgroup-local numbering)
+    uint32_t my_tiles;
+    uint32_t b0, G;                                   // tile numbers fit 32 bits (2^32 tiles = 64 TiB of input)
+    __device__ __forceinline__ uint32_t tile(uint32_t n) const { return b0 + n * G; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// DATA waves (threads 0..255) of the ring-pipelined encoder.  One loop iteration:
+//   phase X  store the OLDEST packed tile if the scout has resolved its offset (funnel shift from its
+//            slot, coalesced dword stores); look up / concatenate / scan the next tile (registers
+//            only) if a staging slot is free; issue the loads of the tile after it
+//   -- data barrier --
+//   phase Y  publish the new tile's bit count, pack it into its slot, publish its tail; clear the
+//            slot that was just stored; thread 0 snapshots the scout's progress
+//   -- data barrier --
+// A tile that fits no staging slot (more than 4 bits per symbol on average) takes the general path
+// once the ring has drained.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& sm, RingCtl c, int tid, int lane, int wave)
 {
-    __shared__ Smem sm;
-    const int tid  = (int)threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    sm.lut[lut_slot((uint32_t)tid)] = p.lut[tid];
-    zero_words(&sm.stage[0][0], 2u * kStageWords / 4u, tid);
-    if (tid == 0) { sm.abort_flag = 0u; sm.ts[0].bits = 0u; sm.ts[1].bits = 0u; }
-
-    uint64_t cur = blockIdx.x;
-    if (cur >= p.num_tiles) return;
-    const uint64_t stride = gridDim.x;
     uint4 raw[kRows];
-    load_tile(p, cur, wave, lane, raw);
-    __syncthreads();
+    load_tile(p, c.b0, c.b0 < p.num_full_tiles, wave, lane, raw);
+    DataBarrier bar;
+    STAMP_DECL;
 
-    bool     has_prev = false;
-    uint64_t prev = 0;
-    uint32_t par = 0;                    // staging buffer / TileState slot of `cur`
-    LbRegs   lb;                         // wave 0: granules requested for `prev`
-
-    for (;;) {
-        const uint64_t nxt = cur + stride;
-        const bool has_nxt = nxt < p.num_tiles;
-        const bool full = (cur + 1) * (uint64_t)kTileWords <= p.num_words;
+    while (c.n_stored < c.my_tiles) {
+        const bool can_pack = c.n_packed < c.my_tiles && (c.n_packed - c.n_stored) < (uint32_t)kSlots;
+        const bool do_store = c.n_stored < c.n_res;
+        const uint32_t sp = c.n_packed % kSlots, ss = c.n_stored % kSlots;
+        const uint32_t cur = c.tile(c.n_packed);
+        STAMP_COUNT(8, 1); STAMP_COUNT(9, can_pack ? 1 : 0); STAMP_COUNT(10, do_store ? 1 : 0);
+        STAMP_COUNT(11, (!can_pack && !do_store) ? 1 : 0);
 
         // ---------------- phase X ----------------
         uint64_t acc[kRows];
         uint32_t tot[kRows], excl[kRows], rowbase[kRows];
-        uint32_t wavetot = 0;
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            if (full) {
-                encode16<true>(raw[r], 4, sm.lut, acc[r], tot[r]);
-            } else {
-                const uint64_t wbase = cur * (uint64_t)kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
-                encode16<false>(raw[r], valid_words(p, wbase), sm.lut, acc[r], tot[r]);
-            }
-            const uint32_t incl = wave_incl_scan(tot[r]);
-            excl[r]    = incl - tot[r];
-            rowbase[r] = wavetot;
-            wavetot   += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-        if (lane == 0) sm.wave_tot[par][wave] = wavetot;
-        if (has_nxt) load_tile(p, nxt, wave, lane, raw);      // raw is dead: its registers take the next tile
-
-        if (has_prev && wave == 0 && !(sm.ts[par ^ 1u].flags & kTsPrefixReady)) {
-            uint64_t P = 0; uint32_t pt = 0;
-            const bool ok = lookback<false, true>(p, prev, (uint64_t)sm.ts[par ^ 1u].bits, lane, lb, P, pt);
-            if (lane == 0) {
-                sm.ts[par ^ 1u].prefix    = P;
-                sm.ts[par ^ 1u].pred_tail = pt;
-                sm.stage[par ^ 1u][0]     = pt;           // carry slot of prev's staging buffer
-                if (!ok) sm.abort_flag = 1u;
-            }
-        }
-        // the buffer `cur` will be packed into was last used two tiles ago (stored one iteration ago)
-        zero_words(sm.stage[par], (sm.ts[par].bits >> 7) + 2u, tid);
-        __syncthreads();                                                      // barrier 1
-        if (sm.abort_flag) return;
-
-        // ---------------- phase Y ----------------
-        const uint32_t c0 = sm.wave_tot[par][0], c1 = sm.wave_tot[par][1],
-                       c2 = sm.wave_tot[par][2], c3 = sm.wave_tot[par][3];
-        const uint32_t T = c0 + c1 + c2 + c3;
-        const bool slow = T > kFastBits;                 // does not fit one staging buffer: general path
-        const uint32_t wavebase = wave == 0 ? 0u : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
-        const bool early_tail = !slow && c3 >= 31u;     // the tile's last 31 bits are all written by wave 3
-        const uint32_t rtile = (uint32_t)(cur & (kGroupTiles - 1));
-        const bool leader = (rtile == kGroupTiles - 1) || (cur == p.num_tiles - 1);
-
-        if (tid == 0) {
-            st_granule(&p.tile_bits[cur], kValid | (uint64_t)T);   // publish before anything else
-            sm.ts[par].bits  = T;
-            sm.ts[par].flags = early_tail ? kTsEarlyTail : 0u;
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < kRows; ++r) sm.ts[par].seg_rel[wave * kRows + r] = wavebase + rowbase[r];
-        }
-
-        if (has_prev) finish_tile(p, sm, prev, par ^ 1u, tid);
-
-        if (!slow) {
-            uint32_t* const st = sm.stage[par] + 1;
+        STAMP(0);
+        if (do_store) { TL(p, c.tile(c.n_stored), 5, tid == 0); finish_tile(p, sm, c.tile(c.n_stored), ss, tid); }
+        STAMP(1);
+        if (can_pack) {
+            const bool full = cur < p.num_full_tiles;
+            uint32_t wavetot = 0;
 #pragma unroll
             for (int r = 0; r < kRows; ++r) {
-                const uint32_t q = wavebase + rowbase[r] + excl[r];
-                if (tot[r] <= 64u) {
-                    put_bits64(st, q, acc[r], tot[r]);
-                } else {                                   // rare: re-read this lane's 16 bytes (L2) and go pairwise
-                    const uint64_t wbase = cur * (uint64_t)kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
-                    const uint32_t* in32 = (const uint32_t*)p.in;
-                    const int n = valid_words(p, wbase);
-                    uint32_t w[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) w[k] = k < n ? in32[wbase + k] : 0u;
-                    put_row_pairs(st, q, w, n, sm.lut);
+                if (full) {
+                    encode16<true>(raw[r], 4, sm.lut, acc[r], tot[r]);
+                } else {
+                    const uint64_t wbase = (uint64_t)cur * kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
+                    encode16<false>(raw[r], valid_words(p, wbase), sm.lut, acc[r], tot[r]);
                 }
+                const uint32_t incl = wave_incl_scan(tot[r]);
+                excl[r]    = incl - tot[r];
+                rowbase[r] = wavetot;
+                wavetot   += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
-            if (early_tail && wave == 3 && lane == 0)   // same-wave LDS ops complete in order
-                st_granule(&p.tile_tail[cur], kValid | (uint64_t)extract_tail(st, T));
+            if (lane == 0) sm.wave_tot[wave] = wavetot;
+            STAMP(2);
+            if (c.n_packed + 1 < c.my_tiles)              // raw is dead: its registers take the next tile
+                load_tile(p, cur + c.G, cur + c.G < p.num_full_tiles, wave, lane, raw);
+        } else if (!do_store) {
+            __builtin_amdgcn_s_sleep(8);                  // ring full and the oldest tile unresolved: wait for the scout
         }
+        STAMP(3);
+        bar.sync(sm, lane);                                                   // data barrier 1
+        STAMP(4);
 
-        if (wave == 0) {
-            if (leader || slow) {
-                // resolve now: a group leader publishes its group's aggregate / prefix without waiting an
-                // iteration; the general path needs its offset before it can store anything
-                uint64_t P = 0; uint32_t pt = 0;
-                const bool ok = lookback<false, true>(p, cur, (uint64_t)T, lane, LbRegs(), P, pt);
-                if (lane == 0) {
-                    sm.ts[par].prefix    = P;
-                    sm.ts[par].pred_tail = pt;
-                    sm.ts[par].flags    |= kTsPrefixReady;
-                    sm.stage[par][0]     = pt;
-                    if (!ok) sm.abort_flag = 1u;
+        // ---------------- phase Y ----------------
+        bool slow = false;
+        if (can_pack) {
+            const uint32_t c0 = sm.wave_tot[0], c1 = sm.wave_tot[1], c2 = sm.wave_tot[2], c3 = sm.wave_tot[3];
+            const uint32_t T = c0 + c1 + c2 + c3;
+            slow = T > kFastBits;                         // fits no staging slot: general path, once the ring is empty
+            const bool early_tail = !slow && c3 >= 31u;   // the tile's last 31 bits are all written by wave 3
+            const uint32_t wavebase = wave == 0 ? 0u : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+            if (tid == 0) {
+                st_granule(&p.tile_bits[cur], kValid | (uint64_t)T);   // publish before anything else
+                TL(p, cur, 0, true);
+                sm.ts[sp].bits  = T;
+                sm.ts[sp].flags = early_tail ? kTsEarlyTail : 0u;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) sm.ts[sp].seg_rel[wave * kRows + r] = wavebase + rowbase[r];
+            }
+            if (!slow) {
+                uint32_t* const st = sm.stage[sp] + 1;
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) {
+                    const uint32_t q = wavebase + rowbase[r] + excl[r];
+                    if (HVLC_DBG(p, kDbgNoPack)) { if (acc[r] == 0x123456789ull) st[q & 1023u] = tot[r]; continue; }
+                    if (tot[r] <= 64u) {
+                        put_bits64(st, q, acc[r], tot[r]);
+                    } else {                               // rare: re-read this lane's 16 bytes (L2) and go pairwise
+                        const uint64_t wbase = (uint64_t)cur * kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
+                        const uint32_t* in32 = (const uint32_t*)p.in;
+                        const int n = valid_words(p, wbase);
+                        uint32_t w[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) w[k] = k < n ? in32[wbase + k] : 0u;
+                        put_row_pairs(st, q, w, n, sm.lut);
+                    }
                 }
-            } else {
-                lookback_issue(p, cur, lane, lb);
+                if (early_tail && wave == 3 && lane == 0)   // same-wave LDS ops complete in order
+                    st_granule(&p.tile_tail[cur], kValid | (uint64_t)extract_tail(st, T));
             }
         }
-        __syncthreads();                                                      // barrier 2
+        STAMP(5);
+        if (do_store) zero_words(sm.stage[ss], (sm.ts[ss].bits >> 7) + 2u, tid);
+        if (tid == 0) sm.n_res_snap = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        STAMP(6);
+        bar.sync(sm, lane);                                                   // data barrier 2
+        STAMP(7);
         if (sm.abort_flag) return;
+        c.n_res = sm.n_res_snap;
+        if (do_store) ++c.n_stored;
+        if (can_pack) {
+            ++c.n_packed;                                 // the scout may now resolve it (its ts[] entry is complete)
+            if (tid == 0) __hip_atomic_store(&sm.n_packed_pub, c.n_packed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
 
         if (slow) {
-            general_tile(p, sm, cur, par, tid, lane, wave);
-            if (tid == 0) { sm.ts[0].bits = 0u; sm.ts[1].bits = 0u; }   // both buffers are clean again
-            has_prev = false;
-        } else {
-            has_prev = true;
-            prev = cur;
+            // Oversized tile: drain the ring (store every older tile), wait for its own offset, then encode
+            // it on the general path.  Its slot index is free by construction (the ring is empty).
+            const uint32_t me = c.n_packed - 1;
+            for (;;) {
+                const bool st_old = c.n_stored < me && c.n_stored < c.n_res;
+                if (st_old) finish_tile(p, sm, c.tile(c.n_stored), c.n_stored % kSlots, tid);
+                else        __builtin_amdgcn_s_sleep(8);
+                bar.sync(sm, lane);
+                if (st_old) zero_words(sm.stage[c.n_stored % kSlots], (sm.ts[c.n_stored % kSlots].bits >> 7) + 2u, tid);
+                if (tid == 0) sm.n_res_snap = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                bar.sync(sm, lane);
+                if (sm.abort_flag) return;
+                c.n_res = sm.n_res_snap;
+                if (st_old) ++c.n_stored;
+                if (c.n_stored == me && c.n_res > me) break;
+            }
+            general_tile(p, sm, bar, cur, sp, tid, lane, wave);
+            ++c.n_stored;
+            bar.sync(sm, lane);
         }
-        if (!has_nxt) break;
-        cur = nxt;
-        par ^= 1u;
-        if (slow) __syncthreads();       // general_tile's final zeroing / ts reset before the next phase X
     }
+    STAMP_DUMP(p.dbg_buf, 0, tid == 0);
+}
 
-    if (has_prev) {                      // drain: the last packed tile of this workgroup
-        const uint32_t pp = par;         // `par` was not flipped after the final iteration
-        if (wave == 0 && !(sm.ts[pp].flags & kTsPrefixReady)) {
-            uint64_t P = 0; uint32_t pt = 0;
-            const bool ok = lookback<false, true>(p, prev, (uint64_t)sm.ts[pp].bits, lane, lb, P, pt);
-            if (lane == 0) {
-                sm.ts[pp].prefix    = P;
-                sm.ts[pp].pred_tail = pt;
-                sm.stage[pp][0]     = pt;
-                if (!ok) sm.abort_flag = 1u;
+// ------------------------------------------------------------------------------------------------
+// SCOUT wave (threads 256..319): all granule polling.  Vector-memory operations retire in order per
+// wave, so a data wave that polled granules would have to drain its HBM prefetch and its stores
+// first; the scout's only memory operations are the 8-byte relaxed agent-scope loads/stores that
+// cross XCDs (2-3 dependent round trips per tile).  It free-runs: it takes no part in the data waves'
+// barrier, resolves the workgroup's tiles in order (blocking, bounded) as soon as they are packed and
+// hands each result over through LDS (release store of n_resolved).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& sm, RingCtl c, int lane)
+{
+    STAMP_DECL;
+    Resolver res[kSlots];               // one look-back in flight per ring slot (static indexing: registers)
+    bool     done[kSlots];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) done[s] = false;
+    uint32_t n_started = 0, n_done = 0; // tiles whose look-back has been started / published to the data waves
+    uint32_t rounds = 0;
+    uint64_t t_progress = 0;
+
+    while (n_done < c.my_tiles) {
+        const uint32_t np = __hip_atomic_load(&sm.n_packed_pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bool progress = false;
+        // request the granules of every newly packed tile at once
+        while (n_started < np && n_started - n_done < (uint32_t)kSlots) {
+            const uint32_t sl = n_started % kSlots;
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s)
+                if ((uint32_t)s == sl) { res[s].start(p, n_started, c.tile(n_started), lane); done[s] = false; TL(p, c.tile(n_started), 1, lane == 0); }
+            ++n_started;
+            progress = true;
+        }
+        STAMP(0);
+        // one non-blocking step of every look-back in flight: evaluate what the previous round requested,
+        // re-request what is still missing (the next round's evaluation waits for it: one round = one round trip)
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            if (res[s].active) {
+                uint64_t P = 0; uint32_t pt = 0;
+                const uint32_t tile = c.tile(res[s].n);
+                const int rc = res[s].step(p, tile, sm.ts[s].bits, lane, false, P, pt);
+                STAMP_COUNT(10, 1);
+                if (p.dbg_tl && lane == 0) { p.dbg_tl[(uint64_t)tile * 8 + 6] += 1; if (rc == 0) p.dbg_tl[(uint64_t)tile * 8 + 7] += (res[s].why == 1u ? 1u : 0u) + (res[s].why & 2u ? 0x100u : 0u) + (res[s].why & 4u ? 0x10000u : 0u); }
+                if (rc == 0) { STAMP_COUNT(11, (res[s].why & 1u) ? 1 : 0); STAMP_COUNT(12, (res[s].why & 2u) ? 1 : 0);
+                               STAMP_COUNT(13, (res[s].why & 4u) ? 1 : 0);
+                               STAMP_COUNT(14, (res[s].why == 2u && ((tile & 63u) == 63u)) ? 1 : 0); }
+                if (rc > 0) {
+                    TL(p, tile, 4, lane == 0);
+                    if (lane == 0) { sm.ts[s].prefix = P; sm.ts[s].pred_tail = pt; sm.stage[s][0] = pt; }
+                    done[s] = true;
+                    progress = true;
+                }
             }
         }
-        __syncthreads();
-        if (sm.abort_flag) return;
-        finish_tile(p, sm, prev, pp, tid);
+        STAMP(1);
+        // hand the resolved tiles over in order
+        uint32_t nd = n_done;
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) {
+            const uint32_t sl = nd % kSlots;
+            bool d = false;
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) if ((uint32_t)s == sl) d = done[s];
+            if (nd < n_started && d) {
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s) if ((uint32_t)s == sl) done[s] = false;
+                ++nd;
+            }
+        }
+        if (nd != n_done) {
+            n_done = nd;
+            if (lane == 0) __hip_atomic_store(&sm.n_resolved, n_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            STAMP_COUNT(8, 1);
+        }
+        STAMP_COUNT(9, 1);
+        if (__hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+        // watchdog: no hand-over for timeout_ticks -> give up (and make every other workgroup give up)
+        if (progress) { rounds = 0; t_progress = 0; }
+        else {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++rounds & 255u) == 0u) {
+                const uint64_t now = __builtin_amdgcn_s_memrealtime();
+                const uint32_t st  = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t_progress == 0) t_progress = now;
+                if ((st & kFlagTimeout) || now - t_progress > p.timeout_ticks) {
+                    atomicOr(p.status, kFlagTimeout);
+                    if (lane == 0) __hip_atomic_store(&sm.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return;
+                }
+            }
+        }
+        STAMP(2);
     }
+    STAMP_DUMP(p.dbg_buf, 1, lane == 0);
+}
+
+// The persistent, ring-pipelined encoder.  A workgroup = 4 DATA waves + 1 SCOUT wave.  It owns tiles
+// b, b+G, b+2G, ... (G = grid size) and keeps up to kSlots of them packed in LDS while the scout
+// resolves their global bit offsets, so HBM latency, the inter-XCD granule round trips and the LDS
+// bit packing of up to kSlots+1 tiles overlap inside one workgroup, on top of the overlap between the
+// workgroups of a CU.
+__global__ void __launch_bounds__(kEncThreads) k_encode(EncodeParams p)
+{
+    __shared__ Smem sm;
+    const int tid   = (int)threadIdx.x;
+    const int lane  = tid & 63;
+    const int wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    if (tid < 256) sm.lut[lut_slot((uint32_t)tid)] = p.lut[tid];
+    if (tid < 256) zero_words(&sm.stage[0][0], (uint32_t)kSlots * kStageWords / 4u, tid);
+    if (tid == 0) { sm.abort_flag = 0u; sm.n_resolved = 0u; sm.n_packed_pub = 0u; sm.n_res_snap = 0u; sm.bar = 0u; }
+    if (tid < kSlots) { sm.ts[tid].bits = 0u; sm.ts[tid].flags = 0u; }
+
+    RingCtl c;
+    c.G = gridDim.x; c.b0 = blockIdx.x;
+    const uint32_t ntiles = (uint32_t)p.num_tiles;
+    if (c.b0 >= ntiles) return;
+    c.my_tiles = (ntiles - c.b0 + c.G - 1) / c.G;
+    __syncthreads();                                  // the only workgroup-wide barrier: LDS initialised
+    if (wave == 4) encode_scout_wave(p, sm, c, lane);
+    else           encode_data_waves(p, sm, c, tid, lane, wave);
 }
 
 // ---------------------------------------------------------------------------------------------

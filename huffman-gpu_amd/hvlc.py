@@ -69,7 +69,7 @@ def lib():
     # torch first: its wheel bundles a HIP runtime with the same soname as /opt/rocm's; libhvlc must bind
     # to the ONE runtime instance that owns the tensors and streams it is handed (a C host links /opt/rocm).
     import torch  # noqa: F401
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(os.environ.get("HVLC_LIB", LIB_PATH))   # HVLC_LIB: developer override (tools/ablate.sh)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     L.hvlc_create.argtypes = [C.POINTER(vp), i32, u64]
     L.hvlc_destroy.argtypes = [vp]

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Developer tool: per-tile timeline (pack -> request -> resolved -> store) from the -DHVLC_EXPERIMENT build."""
+import argparse, ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "huffman-gpu_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["HVLC_LIB"] = os.path.join(ROOT, "huffman-gpu_amd", "libhvlc_exp.so")
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mib", type=int, default=1024); ap.add_argument("--bpc", type=int, default=3)
+    ap.add_argument("--workload", default="H2.2")
+    a = ap.parse_args()
+    import torch, hvlc
+    from util import dist_weights, SEEDS
+    L = hvlc.lib(); L.hvlc_debug_set_timeline.argtypes = [C.c_void_p]
+    period = np.fromfile(os.path.join(ROOT, "tests", "golden", "g1_period.bin"), dtype=np.uint8)
+    n = a.mib << 20
+    os.environ["HVLC_BLOCKS_PER_CU"] = str(a.bpc)
+    enc = hvlc.Encoder(0, n // 4)
+    d_in = enc.gen_symbols(n, SEEDS[a.workload], hvlc.cdf32_from_counts(dist_weights(a.workload, period)))
+    hist = enc.histogram(d_in).cpu().numpy().astype(np.uint64)
+    cw, cl = hvlc.huffman_table(hist); d_tab = enc.table_to_device(cw, cl)
+    out = torch.empty(hvlc.out_capacity_words(n // 4, int(cl.max())), dtype=torch.int32, device="cuda")
+    offs = torch.empty(hvlc.num_segments(n // 4), dtype=torch.int64, device="cuda")
+    ntiles = n // 16384
+    for it in range(3):
+        tl = torch.zeros(ntiles * 8, dtype=torch.int64, device="cuda")
+        L.hvlc_debug_set_timeline(C.c_void_p(tl.data_ptr()))
+        enc.encode_ptr(d_in.data_ptr(), n // 4, d_tab.data_ptr(), d_tab.data_ptr() + 1024, out.data_ptr(), out.numel(), offs.data_ptr(), 0)
+        bits, rc = enc.finish(check=False)
+    t = tl.cpu().numpy().reshape(ntiles, 8).astype(np.float64)
+    G = enc.launch_info()["grid_blocks"]
+    t0 = t[:, 0].min()
+    us = lambda x: (x - t0) / 100.0
+    pack, start, ga_nl, ga_l, res, store, rounds = us(t[:, 0]), us(t[:, 1]), us(t[:, 2]), us(t[:, 3]), us(t[:, 4]), us(t[:, 5]), t[:, 6]
+    print(f"grid {G} tiles {ntiles} rc {rc} span {us(t[:,5].max()):.1f} us")
+    def st(name, x):
+        print(f"  {name:34s} mean {x.mean():7.2f}  p50 {np.percentile(x,50):7.2f}  p90 {np.percentile(x,90):7.2f}  max {x.max():7.2f}")
+    mid = slice(ntiles // 4, 3 * ntiles // 4)
+    st("pack -> scout starts (us)", (start - pack)[mid])
+    st("start -> in-group bits complete", (np.where(t[:, 3] > 0, ga_l, ga_nl) - start)[mid])
+    st("in-group complete -> resolved", (res - np.where(t[:, 3] > 0, ga_l, ga_nl))[mid])
+    st("pack -> resolved", (res - pack)[mid])
+    st("resolved -> store begins", (store - res)[mid])
+    st("pack -> store", (store - pack)[mid])
+    st("scout steps per tile", rounds[mid])
+    lead = np.arange(ntiles) % 64 == 63
+    st("LEADER pack -> GA published", (ga_l - pack)[lead][ntiles // 256: 3 * ntiles // 256])
+    st("LEADER pack -> resolved(GP)", (res - pack)[lead][ntiles // 256: 3 * ntiles // 256])
+    # spread of pack times inside a group, and GA publication relative to the group's last pack
+    pk = pack[: ntiles // 64 * 64].reshape(-1, 64)
+    st("group: last pack - first pack", (pk.max(axis=1) - pk.min(axis=1))[ntiles // 256: 3 * ntiles // 256])
+    gal = ga_l[lead]
+    st("group: GA published - last pack", (gal - pk.max(axis=1))[ntiles // 256: 3 * ntiles // 256])
+    gp = res[lead]
+    st("group: GP published - last pack", (gp - pk.max(axis=1))[ntiles // 256: 3 * ntiles // 256])
+    # generation structure: pack time of local tile n of each WG
+    gen = pack[: ntiles // G * G].reshape(-1, G)
+    print("  generation pack time (mean over WGs) first 12:", np.round(gen.mean(axis=1)[:12], 1))
+    print("  generation pack spread (max-min)   first 12:", np.round((gen.max(axis=1) - gen.min(axis=1))[:12], 1))
+main()
