@@ -102,18 +102,34 @@ int env_int(const char* name, int dflt)
     return (v && *v) ? atoi(v) : dflt;
 }
 
-// Persistent grid: every workgroup must be resident at once (see hvlc_device.hip.h).  The
-// occupancy API can over-report by one block per CU for SGPR-heavy 256-thread kernels on
-// ROCm 7.2 (CDNA4 guide), so one block per CU is given back as margin.
+// Persistent grid: every workgroup must be resident at once (see hvlc_device.hip.h).  The occupancy
+// API is advisory: it can over-report for SGPR-heavy kernels on ROCm 7.2 (CDNA4 guide) and it admits a
+// grid that needs EVERY wave slot of a CU, which only fits if the dispatcher spreads each workgroup's
+// waves perfectly over the 4 SIMDs (observed not to: a 4 x 5-wave grid on exactly 20 slots timed out).
+// So the grid is additionally limited to what leaves one spare wave slot per SIMD.
 template <typename K>
-int pick_blocks_per_cu(hvlc_ctx* c, K kernel, int block_threads, int cap)
+int pick_blocks_per_cu(hvlc_ctx* c, K kernel, int block_threads, size_t dyn_lds, int cap)
 {
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block_threads, 0) != hipSuccess || occ < 1) occ = 2;
-    int b = occ > 1 ? occ - 1 : 1;
-    if (b > cap) b = cap;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block_threads, dyn_lds) != hipSuccess || occ < 1) occ = 2;
+    int lim = occ;
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, (const void*)kernel) == hipSuccess && fa.numRegs > 0) {
+        const int alloc = (fa.numRegs + 7) / 8 * 8;                 // VGPR allocation granule: 8
+        int wps = 512 / alloc; if (wps > 8) wps = 8; if (wps < 1) wps = 1;
+        const int waves_per_block = (block_threads + 63) / 64;
+        const int by_waves = (4 * wps - 4) / waves_per_block;       // keep one slot per SIMD spare
+        if (by_waves < lim) lim = by_waves;
+    } else if (lim > 1) {
+        lim -= 1;
+    }
+    if (lim < 1) lim = 1;
+    int b = lim < cap ? lim : cap;
     const int forced = env_int("HVLC_BLOCKS_PER_CU", 0);
-    if (forced > 0) b = forced <= occ ? forced : occ;   // tuning override, never beyond what the API admits
+    if (forced > 0) {                                 // tuning override; same limit unless explicitly waived
+        const int l2 = env_int("HVLC_ALLOW_FULL_OCC", 0) ? occ : lim;
+        b = forced < l2 ? forced : l2;
+    }
     (void)c;
     return b;
 }
@@ -173,7 +189,7 @@ int hvlc_create(hvlc_ctx** out, int device, uint64_t max_words)
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) { delete c; return HVLC_ERR_HIP; }
     c->cus = prop.multiProcessorCount;
-    c->blocks_per_cu = pick_blocks_per_cu(c, k_encode, kEncThreads, env_int("HVLC_MAX_BLOCKS_PER_CU", 8));
+    c->blocks_per_cu = pick_blocks_per_cu(c, k_encode, kEncThreads, sizeof(Smem), env_int("HVLC_MAX_BLOCKS_PER_CU", 8));
     const int to_ms = env_int("HVLC_TIMEOUT_MS", 2000);
     c->timeout_ticks = (uint64_t)(to_ms > 0 ? to_ms : 2000) * 100000ull;
     int rc = ensure_workspace(c, (max_words + kTileWords - 1) / kTileWords);
@@ -258,7 +274,7 @@ int hvlc_encode(hvlc_ctx* c,
     c->last_grid = (int)grid;
     const bool prof = c->ev && c->ev_used < c->ev_cap;
     if (prof) HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used], s));
-    hipLaunchKernelGGL(k_encode, dim3((unsigned)grid), dim3(kEncThreads), 0, s, p);
+    hipLaunchKernelGGL(k_encode, dim3((unsigned)grid), dim3(kEncThreads), sizeof(Smem), s, p);
     HVLC_HIP(c, hipGetLastError());
     if (prof) { HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used + 1], s)); c->ev_used++; }
     return HVLC_OK;
@@ -395,7 +411,7 @@ int hvlc_exclusive_scan(hvlc_ctx* c, const uint32_t* d_counts, uint64_t n,
     HVLC_HIP(c, hipMemsetAsync(ws_gran(c), 0, l.bytes, s));
     HVLC_HIP(c, hipMemsetAsync(ws_status(c), 0, 16, s));
     static int scan_bpc = 0;
-    if (!scan_bpc) scan_bpc = pick_blocks_per_cu(c, k_exclusive_scan, kThreads, 4);
+    if (!scan_bpc) scan_bpc = pick_blocks_per_cu(c, k_exclusive_scan, kThreads, 0, 4);
     uint64_t grid = (uint64_t)c->cus * (uint64_t)scan_bpc;
     if (grid > tiles) grid = tiles;
     hipLaunchKernelGGL(k_exclusive_scan, dim3((unsigned)grid), dim3(kThreads), 0, s, d_counts, n, d_offsets, d_total, p);

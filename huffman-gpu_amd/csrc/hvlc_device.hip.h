@@ -52,7 +52,10 @@ constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 16
 constexpr int      kGroupTiles  = 64;
 constexpr uint32_t kFastBits    = 65536;                   // bits one staging buffer holds (2048 words)
 constexpr int      kStageWords  = 2064;                    // carry slot + 2048 (64 bit x 1024 lane-rows) + pad
-constexpr int      kSlots       = 4;                       // staging slots (packed tiles in flight) per workgroup
+#ifndef HVLC_SLOTS
+#define HVLC_SLOTS 4
+#endif
+constexpr int      kSlots       = HVLC_SLOTS;                       // staging slots (packed tiles in flight) per workgroup
 constexpr uint32_t kPollAge     = 1;                       // a tile's granules are requested once this many newer tiles are packed
 constexpr uint64_t kValid       = 1ull << 63;
 constexpr uint64_t kStAgg       = 1ull << 62;              // group granule: aggregate of the group
@@ -285,6 +288,7 @@ struct alignas(16) Smem {
     uint32_t  n_resolved;                   // scout -> data: tiles whose global offset is known (in order)
     uint32_t  n_packed_pub;                 // data -> scout: tiles whose bit count / ts[] entry is published
     uint32_t  n_res_snap;                   // data waves: per-iteration snapshot of n_resolved (uniform decisions)
+    uint32_t  abort_snap;                   // ... and of abort_flag: all four data waves must leave in the same iteration
     uint32_t  bar;                          // arrival counter of the data waves' LDS barrier
     uint32_t  abort_flag;
 };
@@ -395,9 +399,10 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
     return true;
 }
 
-// One look-back in progress in the scout wave.  step() is NON-BLOCKING unless told otherwise: it
-// evaluates the granules requested earlier, re-requests exactly those still missing and returns 0,
-// to be called again half an iteration later; 1 = resolved (P / pred_tail valid), -1 = timed out.
+// One look-back in progress in the scout wave, split so that a round of the scout can EVALUATE every
+// look-back in flight first (eval: no memory operation on the common path) and only then REQUEST what
+// is still missing for all of them (repoll): vector-memory operations retire in order per wave, so a
+// load issued between two evaluations would put a full round trip in front of the second one.
 // A group leader (last tile of its group) publishes the group's aggregate as soon as its in-group
 // predecessors are known and the group's inclusive prefix as soon as the group window is resolved:
 // both are on every later tile's critical path.
@@ -407,6 +412,7 @@ struct Resolver {
     uint32_t n = 0;             // workgroup-local tile number
     bool     active = false;
     bool     ga_done = false;
+    bool     miss_d = false, miss_v = false, miss_t = false;   // per lane: what the last eval() found missing
 
     __device__ __forceinline__ void start(const EncodeParams& p, uint32_t n_, uint64_t tile, int lane)
     {
@@ -414,9 +420,9 @@ struct Resolver {
         lookback_issue(p, tile, lane, L);
     }
 
-    uint32_t why = 0;           // diagnostics (experiment build): which granules the last step() was missing
-
-    __device__ __forceinline__ int step(const EncodeParams& p, uint64_t tile, uint32_t T, int lane, bool block,
+    // 1 = resolved (P / pred_tail valid), 0 = something is missing (call repoll, evaluate again next round),
+    // -1 = timed out (only the rare extended-window path can wait)
+    __device__ __forceinline__ int eval(const EncodeParams& p, uint64_t tile, uint32_t T, int lane,
                                         uint64_t& P_out, uint32_t& pred_tail)
     {
         if (HVLC_DBG(p, kDbgNoLookback)) { P_out = tile * 36400ull; pred_tail = 0; active = false; return 1; }
@@ -424,50 +430,37 @@ struct Resolver {
         const uint64_t g = tile / kGroupTiles;
         const bool leader = (r == kGroupTiles - 1) || (tile == p.num_tiles - 1);
         const bool need = (uint32_t)lane < r;
-        const bool need_t = (lane == 0 && tile > 0);
         const int64_t gi = (int64_t)g - 1 - lane;
-        Spin spin;
-        int fp;
-        uint64_t v;
-        for (;;) {
-            v = gi < 0 ? kStPre : L.v;                              // before the stream: inclusive prefix 0
-            const uint64_t pm  = __ballot((v >> 62) == 2);
-            fp = pm ? __builtin_ctzll(pm) : 64;
-            const uint64_t xm  = __ballot((v >> 62) == 0);
-            const uint64_t low = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
-            const bool miss_d = need && !(L.d >> 63);
-            const bool miss_v = ((xm & low) >> lane) & 1ull;
-            const bool miss_t = need_t && !(L.t >> 63);
-            if (!ga_done && !__any(miss_d)) {
-                insum = (uint64_t)wave_sum_u32(need ? (uint32_t)L.d : 0u);
-                if (leader && lane == 0) st_granule(&p.group_desc[g], kStAgg | (insum + T));
-                TL(p, tile, 3, leader && lane == 0);
-                TL(p, tile, 2, !leader && lane == 0);
-                ga_done = true;
-            }
-            if (!__any(miss_d || miss_v || miss_t)) break;
-#ifdef HVLC_EXPERIMENT
-            why = (__any(miss_d) ? 1u : 0u) | (__any(miss_v) ? 2u : 0u) | (__any(miss_t) ? 4u : 0u);
-#endif
-            if (miss_d) L.d = ld_granule(p.tile_bits + (tile - 1 - (uint64_t)lane));
-            if (miss_v) L.v = ld_granule(&p.group_desc[gi]);
-            if (miss_t) L.t = ld_granule(&p.tile_tail[tile - 1]);
-            if (!block) return 0;
-            if (!spin.wait(p)) return -1;
+        const uint64_t v = gi < 0 ? kStPre : L.v;                   // before the stream: inclusive prefix 0
+        const uint64_t pm  = __ballot((v >> 62) == 2);
+        const int fp = pm ? __builtin_ctzll(pm) : 64;
+        const uint64_t xm  = __ballot((v >> 62) == 0);
+        const uint64_t low = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
+        miss_d = need && !(L.d >> 63);
+        miss_v = ((xm & low) >> lane) & 1ull;
+        miss_t = (lane == 0 && tile > 0) && !(L.t >> 63);
+        if (!ga_done && !__any(miss_d)) {
+            insum = (uint64_t)wave_sum_u32(need ? (uint32_t)L.d : 0u);
+            if (leader && lane == 0) st_granule(&p.group_desc[g], kStAgg | (insum + T));
+            TL(p, tile, 3, leader && lane == 0);
+            TL(p, tile, 2, !leader && lane == 0);
+            ga_done = true;
         }
+        if (__any(miss_d || miss_v || miss_t)) return 0;
         uint64_t excl = wave_sum_u64(lane <= fp ? (v & kValMask) : 0ull);
         if (fp == 64) {                                             // no prefix in the nearest 64 groups (rare): keep going
+            Spin spin;
             for (int64_t gb = (int64_t)g - 64; gb > 0; gb -= 64) {
                 const int64_t gj = gb - 1 - lane;
                 uint64_t u = gj < 0 ? kStPre : 0ull;
                 int fq;
                 for (;;) {
                     if (gj >= 0 && (u >> 62) == 0) u = ld_granule(&p.group_desc[gj]);
-                    const uint64_t pm  = __ballot((u >> 62) == 2);
-                    fq = pm ? __builtin_ctzll(pm) : 64;
-                    const uint64_t xm  = __ballot((u >> 62) == 0);
-                    const uint64_t low = fq >= 63 ? ~0ull : ((2ull << fq) - 1ull);
-                    if ((xm & low) == 0) break;
+                    const uint64_t pm2  = __ballot((u >> 62) == 2);
+                    fq = pm2 ? __builtin_ctzll(pm2) : 64;
+                    const uint64_t xm2  = __ballot((u >> 62) == 0);
+                    const uint64_t low2 = fq >= 63 ? ~0ull : ((2ull << fq) - 1ull);
+                    if ((xm2 & low2) == 0) break;
                     if (!spin.wait(p)) return -1;
                 }
                 excl += wave_sum_u64(lane <= fq ? (u & kValMask) : 0ull);
@@ -480,6 +473,14 @@ struct Resolver {
         pred_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.t) & 0x7fffffffu;
         active = false;
         return 1;
+    }
+
+    __device__ __forceinline__ void repoll(const EncodeParams& p, uint64_t tile, int lane)
+    {
+        const int64_t gi = (int64_t)(tile / kGroupTiles) - 1 - lane;
+        if (miss_d) L.d = ld_granule(p.tile_bits + (tile - 1 - (uint64_t)lane));
+        if (miss_v) L.v = ld_granule(&p.group_desc[gi]);
+        if (miss_t) L.t = ld_granule(&p.tile_tail[tile - 1]);
     }
 };
 
@@ -710,6 +711,8 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
                 TL(p, cur, 0, true);
                 sm.ts[sp].bits  = T;
                 sm.ts[sp].flags = early_tail ? kTsEarlyTail : 0u;
+                // the scout needs only the bit count to start this tile's look-back (it never reads the slot)
+                __hip_atomic_store(&sm.n_packed_pub, c.n_packed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (lane == 0) {
 #pragma unroll
@@ -739,17 +742,17 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
         }
         STAMP(5);
         if (do_store) zero_words(sm.stage[ss], (sm.ts[ss].bits >> 7) + 2u, tid);
-        if (tid == 0) sm.n_res_snap = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (tid == 0) {
+            sm.n_res_snap = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            sm.abort_snap = __hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         STAMP(6);
         bar.sync(sm, lane);                                                   // data barrier 2
         STAMP(7);
-        if (sm.abort_flag) return;
+        if (sm.abort_snap) return;                        // uniform: one thread sampled the flag before the barrier
         c.n_res = sm.n_res_snap;
         if (do_store) ++c.n_stored;
-        if (can_pack) {
-            ++c.n_packed;                                 // the scout may now resolve it (its ts[] entry is complete)
-            if (tid == 0) __hip_atomic_store(&sm.n_packed_pub, c.n_packed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        if (can_pack) ++c.n_packed;
 
         if (slow) {
             // Oversized tile: drain the ring (store every older tile), wait for its own offset, then encode
@@ -761,9 +764,12 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
                 else        __builtin_amdgcn_s_sleep(8);
                 bar.sync(sm, lane);
                 if (st_old) zero_words(sm.stage[c.n_stored % kSlots], (sm.ts[c.n_stored % kSlots].bits >> 7) + 2u, tid);
-                if (tid == 0) sm.n_res_snap = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (tid == 0) {
+                    sm.n_res_snap = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    sm.abort_snap = __hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 bar.sync(sm, lane);
-                if (sm.abort_flag) return;
+                if (sm.abort_snap) return;
                 c.n_res = sm.n_res_snap;
                 if (st_old) ++c.n_stored;
                 if (c.n_stored == me && c.n_res > me) break;
@@ -788,49 +794,47 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
 {
     STAMP_DECL;
     Resolver res[kSlots];               // one look-back in flight per ring slot (static indexing: registers)
-    bool     done[kSlots];
+    bool     done[kSlots], pend[kSlots];
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) done[s] = false;
-    uint32_t n_started = 0, n_done = 0; // tiles whose look-back has been started / published to the data waves
+    for (int s = 0; s < kSlots; ++s) { done[s] = false; pend[s] = false; }
+    uint32_t n_started = 0, n_done = 0; // tiles whose look-back has been started / handed to the data waves
     uint32_t rounds = 0;
     uint64_t t_progress = 0;
 
     while (n_done < c.my_tiles) {
-        const uint32_t np = __hip_atomic_load(&sm.n_packed_pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         bool progress = false;
-        // request the granules of every newly packed tile at once
-        while (n_started < np && n_started - n_done < (uint32_t)kSlots) {
-            const uint32_t sl = n_started % kSlots;
-#pragma unroll
-            for (int s = 0; s < kSlots; ++s)
-                if ((uint32_t)s == sl) { res[s].start(p, n_started, c.tile(n_started), lane); done[s] = false; TL(p, c.tile(n_started), 1, lane == 0); }
-            ++n_started;
-            progress = true;
-        }
         STAMP(0);
-        // one non-blocking step of every look-back in flight: evaluate what the previous round requested,
-        // re-request what is still missing (the next round's evaluation waits for it: one round = one round trip)
+        // (1) evaluate every look-back in flight on what the previous round requested: the first use waits
+        //     for all of this wave's outstanding loads at once, so a round costs ONE granule round trip
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
+            pend[s] = false;
             if (res[s].active) {
                 uint64_t P = 0; uint32_t pt = 0;
                 const uint32_t tile = c.tile(res[s].n);
-                const int rc = res[s].step(p, tile, sm.ts[s].bits, lane, false, P, pt);
+                const int rc = res[s].eval(p, tile, sm.ts[s].bits, lane, P, pt);
                 STAMP_COUNT(10, 1);
-                if (p.dbg_tl && lane == 0) { p.dbg_tl[(uint64_t)tile * 8 + 6] += 1; if (rc == 0) p.dbg_tl[(uint64_t)tile * 8 + 7] += (res[s].why == 1u ? 1u : 0u) + (res[s].why & 2u ? 0x100u : 0u) + (res[s].why & 4u ? 0x10000u : 0u); }
-                if (rc == 0) { STAMP_COUNT(11, (res[s].why & 1u) ? 1 : 0); STAMP_COUNT(12, (res[s].why & 2u) ? 1 : 0);
-                               STAMP_COUNT(13, (res[s].why & 4u) ? 1 : 0);
-                               STAMP_COUNT(14, (res[s].why == 2u && ((tile & 63u) == 63u)) ? 1 : 0); }
+#ifdef HVLC_EXPERIMENT
+                if (p.dbg_tl && lane == 0) p.dbg_tl[(uint64_t)tile * 8 + 6] += 1;
+#endif
+                if (rc < 0) {
+                    if (lane == 0) __hip_atomic_store(&sm.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return;
+                }
                 if (rc > 0) {
                     TL(p, tile, 4, lane == 0);
                     if (lane == 0) { sm.ts[s].prefix = P; sm.ts[s].pred_tail = pt; sm.stage[s][0] = pt; }
                     done[s] = true;
                     progress = true;
+                } else {
+                    pend[s] = true;
+                    STAMP_COUNT(11, __any(res[s].miss_d) ? 1 : 0); STAMP_COUNT(12, __any(res[s].miss_v) ? 1 : 0);
+                    STAMP_COUNT(13, __any(res[s].miss_t) ? 1 : 0);
                 }
             }
         }
         STAMP(1);
-        // hand the resolved tiles over in order
+        // (2) hand the resolved tiles over in order
         uint32_t nd = n_done;
 #pragma unroll
         for (int k = 0; k < kSlots; ++k) {
@@ -849,12 +853,25 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             if (lane == 0) __hip_atomic_store(&sm.n_resolved, n_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             STAMP_COUNT(8, 1);
         }
+        // (3) all requests of this round, back to back: what is still missing, and the granules of newly packed tiles
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s)
+            if (pend[s]) res[s].repoll(p, c.tile(res[s].n), lane);
+        const uint32_t np = __hip_atomic_load(&sm.n_packed_pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (n_started < np && n_started - n_done < (uint32_t)kSlots) {
+            const uint32_t sl = n_started % kSlots;
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s)
+                if ((uint32_t)s == sl) { res[s].start(p, n_started, c.tile(n_started), lane); done[s] = false; TL(p, c.tile(n_started), 1, lane == 0); }
+            ++n_started;
+            progress = true;
+        }
         STAMP_COUNT(9, 1);
         if (__hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
-        // watchdog: no hand-over for timeout_ticks -> give up (and make every other workgroup give up)
+        // watchdog: nothing resolved or started for timeout_ticks -> give up (and make every other workgroup give up)
         if (progress) { rounds = 0; t_progress = 0; }
         else {
-            __builtin_amdgcn_s_sleep(2);
+            if (n_started == n_done) __builtin_amdgcn_s_sleep(4);     // nothing in flight: wait for the data waves
             if ((++rounds & 255u) == 0u) {
                 const uint64_t now = __builtin_amdgcn_s_memrealtime();
                 const uint32_t st  = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -876,16 +893,24 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
 // resolves their global bit offsets, so HBM latency, the inter-XCD granule round trips and the LDS
 // bit packing of up to kSlots+1 tiles overlap inside one workgroup, on top of the overlap between the
 // workgroups of a CU.
-__global__ void __launch_bounds__(kEncThreads) k_encode(EncodeParams p)
+#ifndef HVLC_WAVES_PER_EU
+#define HVLC_WAVES_PER_EU 6
+#endif
+// LDS is passed as dynamic shared memory (sizeof(Smem)) so that the register allocator honours the
+// waves-per-SIMD request below instead of the occupancy the static LDS size would imply: 80 VGPRs
+// leave 24 wave slots per CU for the 20 waves of four 5-wave workgroups (slack for co-residency).
+__global__ void __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(HVLC_WAVES_PER_EU, 8)))
+k_encode(EncodeParams p)
 {
-    __shared__ Smem sm;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hvlc_smem_raw[];
+    Smem& sm = *reinterpret_cast<Smem*>(hvlc_smem_raw);
     const int tid   = (int)threadIdx.x;
     const int lane  = tid & 63;
     const int wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     if (tid < 256) sm.lut[lut_slot((uint32_t)tid)] = p.lut[tid];
     if (tid < 256) zero_words(&sm.stage[0][0], (uint32_t)kSlots * kStageWords / 4u, tid);
-    if (tid == 0) { sm.abort_flag = 0u; sm.n_resolved = 0u; sm.n_packed_pub = 0u; sm.n_res_snap = 0u; sm.bar = 0u; }
+    if (tid == 0) { sm.abort_flag = 0u; sm.abort_snap = 0u; sm.n_resolved = 0u; sm.n_packed_pub = 0u; sm.n_res_snap = 0u; sm.bar = 0u; }
     if (tid < kSlots) { sm.ts[tid].bits = 0u; sm.ts[tid].flags = 0u; }
 
     RingCtl c;

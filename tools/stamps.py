@@ -43,5 +43,11 @@ def main():
         print(f"  scout rounds/WG {s[:,9].mean():.1f} handovers/WG {s[:,8].mean():.1f} steps/WG {s[:,10].mean():.1f} "
               f"incomplete: tile_bits {s[:,11].mean():.1f} group {s[:,12].mean():.1f} tail {s[:,13].mean():.1f} leader-group-only {s[:,14].mean():.1f}")
         print("  scout      cycles/iter: " + ", ".join(f"{nm}={s[:,i].mean()/iters:.0f}" for i, nm in enumerate(names_s)) + f"  total={tots/iters:.0f}")
+        idle = d[:, 11] / d[:, 8]
+        busy = (d[:, 1] + d[:, 2] + d[:, 3] + d[:, 5] + d[:, 6]) / d[:, 9]      # cycles of real work per packed tile
+        print(f"  idle fraction per WG: min {idle.min():.2f} p10 {np.percentile(idle,10):.2f} p50 {np.percentile(idle,50):.2f} p90 {np.percentile(idle,90):.2f} max {idle.max():.2f}")
+        print(f"  work cycles per tile per WG: min {busy.min():.0f} p50 {np.percentile(busy,50):.0f} p90 {np.percentile(busy,90):.0f} max {busy.max():.0f}")
+        by_xcd = [idle[x::8].mean() for x in range(8)]
+        print("  idle fraction by blockIdx%8:", np.round(by_xcd, 2))
         enc.close()
 main()
