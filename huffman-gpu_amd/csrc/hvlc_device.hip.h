@@ -93,8 +93,13 @@ enum : uint32_t { kDbgNoLookback = 1u, kDbgNoStore = 2u, kDbgNoPack = 4u, kDbgNo
 // diagnostic phase timer (never in the product build): accumulates s_memtime deltas per phase
 struct Stamps {
     uint64_t last, acc[16];
+#ifdef HVLC_NO_CLOCK      // counters only (keeps the register footprint of the product build)
+    __device__ __forceinline__ void init() { for (int i = 0; i < 16; ++i) acc[i] = 0; last = 0; }
+    __device__ __forceinline__ void lap(int) { }
+#else
     __device__ __forceinline__ void init() { for (int i = 0; i < 16; ++i) acc[i] = 0; last = clock64(); }
     __device__ __forceinline__ void lap(int i) { const uint64_t t = clock64(); acc[i] += t - last; last = t; }
+#endif
     __device__ __forceinline__ void count(int i, uint64_t v = 1) { acc[i] += v; }
     __device__ __forceinline__ void dump(uint64_t* buf, int which) {
         if (buf) for (int i = 0; i < 16; ++i) buf[((uint64_t)blockIdx.x * 2 + which) * 16 + i] = acc[i];
@@ -179,7 +184,7 @@ struct Spin {
         __builtin_amdgcn_s_sleep(1);
         if ((++n & 1023u) == 0u) {
             const uint64_t now = __builtin_amdgcn_s_memrealtime();
-            const uint32_t st  = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t st  = atomicOr(p.status, 0u);     // RMW: coherent with the other workgroups' atomicOr
             if (t0 == 0) t0 = now;
             if ((st & kFlagTimeout) || now - t0 > p.timeout_ticks) {
                 atomicOr(p.status, kFlagTimeout);
@@ -874,7 +879,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             if (n_started == n_done) __builtin_amdgcn_s_sleep(4);     // nothing in flight: wait for the data waves
             if ((++rounds & 255u) == 0u) {
                 const uint64_t now = __builtin_amdgcn_s_memrealtime();
-                const uint32_t st  = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t st  = atomicOr(p.status, 0u);  // RMW: coherent with the other workgroups' atomicOr
                 if (t_progress == 0) t_progress = now;
                 if ((st & kFlagTimeout) || now - t_progress > p.timeout_ticks) {
                     atomicOr(p.status, kFlagTimeout);
@@ -950,7 +955,9 @@ __global__ void __launch_bounds__(kThreads) k_prepare(const uint32_t* cw, const 
                 if (out_cap >= 1) out_if_empty[0] = 0u; else f |= kFlagCapacity;
                 if (total_if_empty) *total_if_empty = 0ull;
             }
-            status[0] = f;
+            // every access to the status word is an atomic RMW (set by atomicOr from any XCD, read back the same
+            // way): a plain store here was observed to leave a stale flag visible to the next launch
+            (void)atomicExch(&status[0], f);
         }
     }
     for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < granule_vecs; i += (uint64_t)gridDim.x * kThreads)

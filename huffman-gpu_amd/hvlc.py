@@ -267,6 +267,24 @@ def gpu_vlc_encode(indata, codewords, codewordlens):
 
 
 # ------------------------------------------------------------------------------------------
+# host logic: sharding a stream over ranks (SURVEY.md section 8(e)) -- shards are cut at multiples of one
+# 1024-byte segment so that every rank's segment offsets are a contiguous slice of the global ones
+# ------------------------------------------------------------------------------------------
+def shard_bounds(total_words, world, rank):
+    """[first_word, last_word) of rank's shard: equal numbers of whole segments, remainder to the low ranks."""
+    segs = (int(total_words) + SEGMENT_WORDS - 1) // SEGMENT_WORDS
+    per, extra = divmod(segs, world)
+    s0 = rank * per + min(rank, extra)
+    s1 = s0 + per + (1 if rank < extra else 0)
+    return min(s0 * SEGMENT_WORDS, total_words), min(s1 * SEGMENT_WORDS, total_words)
+
+
+def stitch_base(shard_total_bits, rank):
+    """Exclusive prefix of the all-gathered per-shard bit totals: the global bit offset of rank's shard."""
+    return int(sum(int(b) for b in list(shard_total_bits)[:rank]))
+
+
+# ------------------------------------------------------------------------------------------
 # host logic: code-table construction (feeds the encoder; not on the encode path)
 # ------------------------------------------------------------------------------------------
 def huffman_lengths(counts, max_len=MAX_CODE_LEN):

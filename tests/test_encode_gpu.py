@@ -234,6 +234,24 @@ def test_repeatable_and_idempotent(enc, golden):
         assert b2 == b1 and torch.equal(o2[: b1 // 32 + 1], a) and torch.equal(f2, fa)
 
 
+def test_back_to_back_different_data_same_size(enc, golden):
+    """Granule hygiene across launches: alternate two different inputs of identical size (identical granule
+    addresses, different values) on one context; every call must match the oracle."""
+    rng = np.random.default_rng(99)
+    cw, cl = random_table(rng, "short")
+    d_tab = enc.table_to_device(cw, cl)
+    for nwords in (4096 * 70, 4096 * 3 + 5):
+        a = rng.integers(0, 1 << 32, nwords, dtype=np.uint64).astype(np.uint32)
+        b = rng.integers(0, 1 << 32, nwords, dtype=np.uint64).astype(np.uint32)
+        ra, rb = O.encode(a, cw, cl), O.encode(b, cw, cl)
+        da, db = _dev(a), _dev(b)
+        for k in range(6):
+            d, (ref, rbits) = (da, ra) if k % 2 == 0 else (db, rb)
+            out, _, bits = enc.encode(d, d_tab, max_len=int(cl.max()))
+            assert bits == rbits
+            assert np.array_equal(out[: bits // 32 + 1].cpu().numpy().view(np.uint32), ref), (nwords, k)
+
+
 def test_stage_entry_points(enc, golden):
     """hvlc_segment_bits (A1's outidx) and hvlc_exclusive_scan (A3) as separate stages."""
     x = np.tile(golden["period"], 4).view(np.uint32)
@@ -254,6 +272,53 @@ def test_exclusive_scan_sizes(enc, n):
     offs, total = enc.exclusive_scan(_dev(c))
     ref = np.concatenate([[0], np.cumsum(c.astype(np.uint64))])
     assert np.array_equal(offs.cpu().numpy().view(np.uint64), ref[:-1]) and int(total.item()) == int(ref[-1])
+
+
+def test_stitch_two_shards_one_gpu(enc, golden):
+    """The multi-GPU stitch on one device: two shards encoded independently, totals 'all-gathered' into a
+    device array, offsets rebased on the device (hvlc_rebase_offsets_dev) == single-stream offsets."""
+    x = np.tile(golden["period"], 4).view(np.uint32)[: 200_000 + 123]
+    d_tab = enc.table_to_device(golden["cw"], golden["cl"])
+    _, ref_offs, ref_bits = O.segment_offsets(x, golden["cl"])
+    parts, totals = [], []
+    for r in range(2):
+        w0, w1 = hvlc.shard_bounds(x.size, 2, r)
+        out, offs, bits = enc.encode(_dev(x[w0:w1]), d_tab, max_len=21)
+        ref, rbits = O.encode(x[w0:w1], golden["cw"], golden["cl"])
+        assert bits == rbits and np.array_equal(out[: bits // 32 + 1].cpu().numpy().view(np.uint32), ref)
+        parts.append(offs.clone()); totals.append(bits)
+    gathered = torch.tensor(totals, dtype=torch.int64, device="cuda")
+    for r in range(2):
+        enc.rebase_offsets_dev(parts[r], gathered, r)
+    got = torch.cat(parts).cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, ref_offs) and sum(totals) == ref_bits
+
+
+def test_timeout_is_reported_not_a_hang(golden, monkeypatch):
+    """A grid that cannot be co-resident (forced 4x over-subscription) must end in HVLC_ERR_TIMEOUT within
+    the configured bound, not in a hung GPU; a normal encode on a fresh context works afterwards."""
+    import time
+    monkeypatch.setenv("HVLC_TIMEOUT_MS", "200")
+    e2 = hvlc.Encoder(0, 1 << 24)
+    info = e2.launch_info()
+    forced = 2 * info["compute_units"] * info["blocks_per_cu"]   # twice what can be resident, two+ tiles each:
+    monkeypatch.setenv("HVLC_TEST_FORCE_GRID", str(forced))      # resident workgroups wait for queued ones forever
+    x = np.tile(golden["period"], 256).view(np.uint32)          # 64 MiB = 4096 tiles
+    d_in = _dev(x); d_tab = e2.table_to_device(golden["cw"], golden["cl"])
+    out = torch.empty(hvlc.out_capacity_words(x.size, 21), dtype=torch.int32, device="cuda")
+    t0 = time.time()
+    e2.encode_ptr(d_in.data_ptr(), x.size, d_tab.data_ptr(), d_tab.data_ptr() + 1024, out.data_ptr(), out.numel())
+    _, rc = e2.finish(check=False)
+    dt = time.time() - t0
+    assert rc == hvlc.ERR_TIMEOUT, rc
+    assert dt < 5.0, dt
+    monkeypatch.delenv("HVLC_TEST_FORCE_GRID")
+    e2.close()
+    e3 = hvlc.Encoder(0, 1 << 24)
+    o3, _, bits = e3.encode(d_in, d_tab, max_len=21)
+    ref, rbits = O.encode(x, golden["cw"], golden["cl"])
+    assert bits == rbits and torch.equal(o3[: bits // 32 + 1].cpu(), torch.from_numpy(ref.view(np.int32)))
+    e3.close()
 
 
 def test_generator_and_histogram_match_oracle(enc, golden):
