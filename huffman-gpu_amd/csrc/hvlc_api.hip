@@ -57,12 +57,18 @@ constexpr uint64_t kHeaderBytes = kLutBytes + kStatusBytes;
 inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
 // granule layout for `tiles` tiles: tile_bits | tile_tail | group_desc, each padded to 16 B
-struct Layout { uint64_t tiles_pad, groups_pad, bytes; };
+// (the arrays are addressed transposed, kGranRows x tile_cols and kGranRowsG x group_cols: hvlc_device.hip.h)
+struct Layout { uint64_t tiles_pad, groups_pad, bytes; uint32_t tile_cols, group_cols; };
 inline Layout layout_for(uint64_t tiles)
 {
     Layout l;
-    l.tiles_pad  = round_up(tiles ? tiles : 1, 2);
-    l.groups_pad = round_up((tiles + kGroupTiles - 1) / kGroupTiles + 1, 2);
+    const uint64_t groups = (tiles + kGroupTiles - 1) / kGroupTiles + 1;
+    l.tile_cols  = (uint32_t)((tiles + kGranRows - 1) / kGranRows);
+    if (l.tile_cols < 1) l.tile_cols = 1;
+    l.group_cols = (uint32_t)((groups + kGranRowsG - 1) / kGranRowsG);
+    if (l.group_cols < 1) l.group_cols = 1;
+    l.tiles_pad  = (uint64_t)kGranRows * l.tile_cols;
+    l.groups_pad = (uint64_t)kGranRowsG * l.group_cols;
     l.bytes      = (2 * l.tiles_pad + l.groups_pad) * 8;
     return l;
 }
@@ -91,6 +97,8 @@ void fill_granule_ptrs(hvlc_ctx* c, uint64_t tiles, EncodeParams& p)
     p.tile_bits  = g;
     p.tile_tail  = g + l.tiles_pad;
     p.group_desc = g + 2 * l.tiles_pad;
+    p.tile_cols  = l.tile_cols;
+    p.group_cols = l.group_cols;
     p.status     = ws_status(c);
     p.result     = ws_result(c);
     p.timeout_ticks = c->timeout_ticks;
@@ -280,6 +288,12 @@ int hvlc_encode(hvlc_ctx* c,
     const int forced_grid = env_int("HVLC_TEST_FORCE_GRID", 0);
     if (forced_grid > 0) grid = (uint64_t)forced_grid;
     if (grid > tiles) grid = tiles;
+    // Tile t belongs to workgroup t % grid and the LAST tile of every 64-tile group does that group's share of
+    // the look-back (it waits for all 63 predecessors and publishes the aggregate / prefix everybody else
+    // needs).  With a grid that is a multiple of 64 the same grid/64 workgroups would own every such tile and
+    // the whole chip would run at their pace (measured: 2 groups/us whatever the tile size).  An odd grid
+    // rotates that role over all workgroups.
+    if (grid > 64 && (grid & 1u) == 0u) grid -= 1;
     c->last_grid = (int)grid;
     const bool prof = c->ev && c->ev_used < c->ev_cap;
     if (prof) HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used], s));
@@ -405,7 +419,7 @@ int hvlc_exclusive_scan(hvlc_ctx* c, const uint32_t* d_counts, uint64_t n,
     if (!c || (n && (!d_counts || !d_offsets))) return HVLC_ERR_ARG;
     HVLC_HIP(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    const uint64_t tiles = (n + kTileWords - 1) / kTileWords;
+    const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
     if (tiles == 0) {
         if (d_total) HVLC_HIP(c, hipMemsetAsync(d_total, 0, 8, s));
         return HVLC_OK;

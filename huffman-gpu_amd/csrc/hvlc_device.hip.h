@@ -42,21 +42,32 @@
 
 namespace hvlc {
 
-constexpr int      kThreads     = 256;                     // data threads of the encoder (4 waves) / block size of the small kernels
-constexpr int      kEncThreads  = 320;                     // k_encode: 4 data waves + 1 scout wave
-constexpr int      kRows        = 4;                       // 16-byte rows per lane per tile
-constexpr int      kTileWords   = kThreads * kRows * 4;    // 4096 words = 16 KiB
-constexpr int      kTileVec     = kThreads * kRows;        // 1024 uint4
+constexpr int      kThreads     = 256;                     // block size of the small kernels
+#ifndef HVLC_DATA_WAVES
+#define HVLC_DATA_WAVES 3
+#endif
+constexpr int      kDataWaves   = HVLC_DATA_WAVES;         // data waves per encoder workgroup (+1 scout wave)
+constexpr int      kDataThreads = 64 * kDataWaves;
+constexpr int      kEncThreads  = kDataThreads + 64;       // k_encode: with 3+1 waves a workgroup is one wave per SIMD
+#ifndef HVLC_ROWS
+#define HVLC_ROWS 4
+#endif
+constexpr int      kRows        = HVLC_ROWS;               // 16-byte rows per lane per tile
+constexpr int      kTileWords   = kDataThreads * kRows * 4;   // 3072 words = 12 KiB
+constexpr int      kTileVec     = kDataThreads * kRows;    // uint4s per tile
 constexpr int      kSegWords    = 256;
-constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 16
+constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 12: wave w owns segments 4w..4w+3
 constexpr int      kGroupTiles  = 64;
-constexpr uint32_t kFastBits    = 65536;                   // bits one staging buffer holds (2048 words)
-constexpr int      kStageWords  = 2064;                    // carry slot + 2048 (64 bit x 1024 lane-rows) + pad
+constexpr int      kScanTile    = 4096;                    // elements per workgroup pass of k_exclusive_scan
+constexpr uint32_t kFastBits    = (uint32_t)kDataThreads * kRows * 64u;    // bits one staging slot holds (64 per lane-row)
+constexpr int      kStageWords  = (int)(kFastBits / 32u) + 16;             // carry slot + data + pad (multiple of 4)
 #ifndef HVLC_SLOTS
-#define HVLC_SLOTS 4
+#define HVLC_SLOTS 3
 #endif
 constexpr int      kSlots       = HVLC_SLOTS;                       // staging slots (packed tiles in flight) per workgroup
 constexpr uint32_t kPollAge     = 1;                       // a tile's granules are requested once this many newer tiles are packed
+constexpr int      kGranRows    = 256;                     // rows of the transposed granule layout (tiles); groups use 64
+constexpr int      kGranRowsG   = 64;
 constexpr uint64_t kValid       = 1ull << 63;
 constexpr uint64_t kStAgg       = 1ull << 62;              // group granule: aggregate of the group
 constexpr uint64_t kStPre       = 2ull << 62;              // group granule: inclusive prefix through the group
@@ -80,6 +91,8 @@ struct EncodeParams {
     uint64_t*       tile_bits;   // granule per tile: kValid | bits
     uint64_t*       tile_tail;   // granule per tile: kValid | last 31 bits of the stream through this tile
     uint64_t*       group_desc;  // granule per group: status | value
+    uint32_t        tile_cols;   // granule arrays are stored TRANSPOSED: tile t at (t % kGranRows) * tile_cols + t / kGranRows,
+    uint32_t        group_cols;  // so that the granules of consecutive tiles lie kilobytes apart (different memory channels)
     uint64_t        timeout_ticks;   // s_memrealtime ticks (100 MHz)
     uint32_t        dbg;             // ablation flags, honoured only in -DHVLC_EXPERIMENT builds (tools/)
     uint64_t*       dbg_buf;         // phase stamps [grid][2][16], -DHVLC_EXPERIMENT builds only
@@ -124,6 +137,19 @@ struct Stamps {
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
+// Granule addressing.  Consecutive tiles are resolved by workgroups all over the chip at about the same
+// time; with a linear array their 8-byte granules share 64-byte lines and one memory channel, and the
+// stores and polls of the active window serialise there (measured: ~120 tiles/us chip-wide whatever the
+// tile size).  The transposed layout puts consecutive tiles tile_cols * 8 bytes apart.
+__device__ __forceinline__ uint64_t tix(const EncodeParams& p, uint64_t t)
+{
+    return (t & (uint64_t)(kGranRows - 1)) * p.tile_cols + (t / kGranRows);
+}
+__device__ __forceinline__ uint64_t gix(const EncodeParams& p, uint64_t g)
+{
+    return (g & (uint64_t)(kGranRowsG - 1)) * p.group_cols + (g / kGranRowsG);
+}
+
 __device__ __forceinline__ uint64_t ld_granule(const uint64_t* p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -287,9 +313,9 @@ enum : uint32_t { kTsEarlyTail = 1u, kTsPrefixReady = 2u };
 struct alignas(16) Smem {
     uint2     lut[256];                     // 2 KiB: {codeword, length}
     uint32_t  stage[kSlots][kStageWords];   // ring of staging slots; [s][0] is the carry slot
-    uint32_t  wave_tot[4];                  // per-wave bit totals of the tile being packed
+    uint32_t  wave_tot[kDataWaves];         // per-wave bit totals of the tile being packed
     TileState ts[kSlots];
-    uint32_t  qtot[4];                      // general path: per-wave totals of a quarter tile
+    uint32_t  qtot[kDataWaves];             // general path: per-wave totals of a quarter tile
     uint32_t  n_resolved;                   // scout -> data: tiles whose global offset is known (in order)
     uint32_t  n_packed_pub;                 // data -> scout: tiles whose bit count / ts[] entry is published
     uint32_t  n_res_snap;                   // data waves: per-iteration snapshot of n_resolved (uniform decisions)
@@ -306,7 +332,7 @@ struct DataBarrier {
     uint32_t target = 0;
     __device__ __forceinline__ void sync(Smem& sm, int lane)
     {
-        target += 4u;
+        target += (uint32_t)kDataWaves;
         if (lane == 0) (void)__hip_atomic_fetch_add(&sm.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         while (__hip_atomic_load(&sm.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) { }
     }
@@ -324,10 +350,13 @@ __device__ __forceinline__ void lookback_issue(const EncodeParams& p, uint64_t t
 {
     const uint32_t r = (uint32_t)(tile & (kGroupTiles - 1));
     const int64_t  gi = (int64_t)(tile / kGroupTiles) - 1 - lane;
+    const bool leader = (r == kGroupTiles - 1) || (tile == p.num_tiles - 1);
     if (HVLC_DBG(p, kDbgNoLookback)) return;
-    L.d = (uint32_t)lane < r ? ld_granule(p.tile_bits + (tile - 1 - (uint64_t)lane)) : 0ull;
-    L.v = gi >= 0 ? ld_granule(&p.group_desc[gi]) : 0ull;
-    L.t = (lane == 0 && tile > 0) ? ld_granule(&p.tile_tail[tile - 1]) : 0ull;
+    L.d = (uint32_t)lane < r ? ld_granule(p.tile_bits + tix(p, tile - 1 - (uint64_t)lane)) : 0ull;
+    // only a group's last tile walks the 64-group window; everybody else waits for the previous group's
+    // inclusive prefix (one granule): thousands of scouts polling the same few lines was the rate limit
+    L.v = (gi >= 0 && (leader || lane == 0)) ? ld_granule(&p.group_desc[gix(p, (uint64_t)gi)]) : 0ull;
+    L.t = (lane == 0 && tile > 0) ? ld_granule(&p.tile_tail[tix(p, tile - 1)]) : 0ull;
 }
 
 // Two-level decoupled look-back, executed by ONE wave with all 64 lanes active.
@@ -437,16 +466,24 @@ struct Resolver {
         const bool need = (uint32_t)lane < r;
         const int64_t gi = (int64_t)g - 1 - lane;
         const uint64_t v = gi < 0 ? kStPre : L.v;                   // before the stream: inclusive prefix 0
-        const uint64_t pm  = __ballot((v >> 62) == 2);
-        const int fp = pm ? __builtin_ctzll(pm) : 64;
-        const uint64_t xm  = __ballot((v >> 62) == 0);
-        const uint64_t low = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
+        int fp;
+        if (leader) {
+            // the nearest inclusive prefix in the window plus the aggregates after it
+            const uint64_t pm  = __ballot((v >> 62) == 2);
+            fp = pm ? __builtin_ctzll(pm) : 64;
+            const uint64_t xm  = __ballot((v >> 62) == 0);
+            const uint64_t low = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
+            miss_v = ((xm & low) >> lane) & 1ull;
+        } else {
+            // the previous group's inclusive prefix, published by that group's last tile
+            fp = 0;
+            miss_v = (lane == 0) && (v >> 62) != 2;
+        }
         miss_d = need && !(L.d >> 63);
-        miss_v = ((xm & low) >> lane) & 1ull;
         miss_t = (lane == 0 && tile > 0) && !(L.t >> 63);
         if (!ga_done && !__any(miss_d)) {
             insum = (uint64_t)wave_sum_u32(need ? (uint32_t)L.d : 0u);
-            if (leader && lane == 0) st_granule(&p.group_desc[g], kStAgg | (insum + T));
+            if (leader && lane == 0) st_granule(&p.group_desc[gix(p, g)], kStAgg | (insum + T));
             TL(p, tile, 3, leader && lane == 0);
             TL(p, tile, 2, !leader && lane == 0);
             ga_done = true;
@@ -460,7 +497,7 @@ struct Resolver {
                 uint64_t u = gj < 0 ? kStPre : 0ull;
                 int fq;
                 for (;;) {
-                    if (gj >= 0 && (u >> 62) == 0) u = ld_granule(&p.group_desc[gj]);
+                    if (gj >= 0 && (u >> 62) == 0) u = ld_granule(&p.group_desc[gix(p, (uint64_t)gj)]);
                     const uint64_t pm2  = __ballot((u >> 62) == 2);
                     fq = pm2 ? __builtin_ctzll(pm2) : 64;
                     const uint64_t xm2  = __ballot((u >> 62) == 0);
@@ -473,7 +510,7 @@ struct Resolver {
             }
         }
         const uint64_t P = excl + insum;
-        if (leader && lane == 0) st_granule(&p.group_desc[g], kStPre | (P + T));
+        if (leader && lane == 0) st_granule(&p.group_desc[gix(p, g)], kStPre | (P + T));
         P_out = P;
         pred_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.t) & 0x7fffffffu;
         active = false;
@@ -483,9 +520,9 @@ struct Resolver {
     __device__ __forceinline__ void repoll(const EncodeParams& p, uint64_t tile, int lane)
     {
         const int64_t gi = (int64_t)(tile / kGroupTiles) - 1 - lane;
-        if (miss_d) L.d = ld_granule(p.tile_bits + (tile - 1 - (uint64_t)lane));
-        if (miss_v) L.v = ld_granule(&p.group_desc[gi]);
-        if (miss_t) L.t = ld_granule(&p.tile_tail[tile - 1]);
+        if (miss_d) L.d = ld_granule(p.tile_bits + tix(p, tile - 1 - (uint64_t)lane));
+        if (miss_v) L.v = ld_granule(&p.group_desc[gix(p, (uint64_t)gi)]);
+        if (miss_t) L.t = ld_granule(&p.tile_tail[tix(p, tile - 1)]);
     }
 };
 
@@ -494,7 +531,7 @@ struct Resolver {
 __device__ __forceinline__ void store_words(const EncodeParams& p, const uint32_t* sb, uint32_t s,
                                             uint64_t ow, uint32_t nown, int tid)
 {
-    for (uint32_t k = (uint32_t)tid; k < nown; k += kThreads) {
+    for (uint32_t k = (uint32_t)tid; k < nown; k += kDataThreads) {
         const uint32_t v = __builtin_amdgcn_alignbit(sb[k], sb[k + 1], s);
         const uint64_t idx = ow + k;
         if (HVLC_DBG(p, kDbgNoStore)) { if (v == 0x12345u) p.out[0] = v; continue; }
@@ -506,7 +543,7 @@ __device__ __forceinline__ void store_words(const EncodeParams& p, const uint32_
 __device__ __forceinline__ void zero_words(uint32_t* base, uint32_t n_vec4, int tid)
 {
     uint4* z = (uint4*)base;
-    for (uint32_t i = (uint32_t)tid; i < n_vec4; i += kThreads) z[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = (uint32_t)tid; i < n_vec4; i += kDataThreads) z[i] = make_uint4(0, 0, 0, 0);
 }
 
 // Loads of one tile: lane-row r of wave w = segment 4w+r, 16 bytes per lane, 1 KiB per wave-instruction,
@@ -568,7 +605,7 @@ __device__ __forceinline__ void finish_tile(const EncodeParams& p, Smem& sm, uin
     if (!(ts.flags & kTsEarlyTail) && tid == 0) {
         const uint32_t own  = extract_tail(sb + 1, T);
         const uint32_t tail = T >= 31u ? own : (((ts.pred_tail << T) | own) & 0x7fffffffu);
-        st_granule(&p.tile_tail[tile], kValid | (uint64_t)tail);
+        st_granule(&p.tile_tail[tix(p, tile)], kValid | (uint64_t)tail);
     }
 }
 
@@ -595,10 +632,10 @@ __device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, Da
         p.result[0] = Pq + T;
         if (p.total_bits) *p.total_bits = Pq + T;
     }
-    for (int qd = 0; qd < 4; ++qd) {
+    for (int qd = 0; qd < kRows; ++qd) {
         bar.sync(sm, lane);                            // previous quarter fully stored
         zero_words(big, 2u * kStageWords / 4u, tid);
-        const uint64_t wbase = word0 + (uint64_t)qd * 1024u + (uint64_t)tid * 4u;
+        const uint64_t wbase = word0 + (uint64_t)qd * (kDataThreads * 4u) + (uint64_t)tid * 4u;
         const uint32_t* in32 = (const uint32_t*)p.in;
         const int n = valid_words(p, wbase);
         uint32_t w[4];
@@ -615,14 +652,15 @@ __device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, Da
         const uint32_t incl = wave_incl_scan(tq);
         if (lane == 63) sm.qtot[wave] = incl;
         bar.sync(sm, lane);
-        const uint32_t q0 = sm.qtot[0], q1 = sm.qtot[1], q2 = sm.qtot[2], q3 = sm.qtot[3];
-        const uint32_t Tq = q0 + q1 + q2 + q3;
-        const uint32_t pos = (incl - tq) + (wave == 0 ? 0u : wave == 1 ? q0 : wave == 2 ? q0 + q1 : q0 + q1 + q2);
+        uint32_t Tq = 0, qbase = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kDataWaves; ++w2) { const uint32_t q = sm.qtot[w2]; if (w2 < wave) qbase += q; Tq += q; }
+        const uint32_t pos = (incl - tq) + qbase;
         if (tid == 0) big[0] = carry;
         put_row_pairs(big + 1, pos, w, n, sm.lut);
         bar.sync(sm, lane);
         const uint32_t s = (uint32_t)Pq & 31u;
-        const bool lastq = last && qd == 3;
+        const bool lastq = last && qd == kRows - 1;
         uint32_t nown = (s + Tq) >> 5;
         if (lastq) nown = ((s + Tq + 31u) >> 5) + ((((s + Tq) & 31u) == 0u) ? 1u : 0u);
         store_words(p, big, s, Pq >> 5, nown, tid);
@@ -631,7 +669,7 @@ __device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, Da
         Pq += Tq;
     }
     bar.sync(sm, lane);
-    if (tid == 0) st_granule(&p.tile_tail[tile], kValid | (uint64_t)carry);
+    if (tid == 0) st_granule(&p.tile_tail[tix(p, tile)], kValid | (uint64_t)carry);
     zero_words(big, 2u * kStageWords / 4u, tid);
 }
 
@@ -706,13 +744,13 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
         // ---------------- phase Y ----------------
         bool slow = false;
         if (can_pack) {
-            const uint32_t c0 = sm.wave_tot[0], c1 = sm.wave_tot[1], c2 = sm.wave_tot[2], c3 = sm.wave_tot[3];
-            const uint32_t T = c0 + c1 + c2 + c3;
+            uint32_t T = 0, wavebase = 0, clast = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < kDataWaves; ++w2) { clast = sm.wave_tot[w2]; if (w2 < wave) wavebase += clast; T += clast; }
             slow = T > kFastBits;                         // fits no staging slot: general path, once the ring is empty
-            const bool early_tail = !slow && c3 >= 31u;   // the tile's last 31 bits are all written by wave 3
-            const uint32_t wavebase = wave == 0 ? 0u : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+            const bool early_tail = !slow && clast >= 31u;   // the tile's last 31 bits are all written by the last data wave
             if (tid == 0) {
-                st_granule(&p.tile_bits[cur], kValid | (uint64_t)T);   // publish before anything else
+                st_granule(&p.tile_bits[tix(p, cur)], kValid | (uint64_t)T);   // publish before anything else
                 TL(p, cur, 0, true);
                 sm.ts[sp].bits  = T;
                 sm.ts[sp].flags = early_tail ? kTsEarlyTail : 0u;
@@ -741,8 +779,8 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
                         put_row_pairs(st, q, w, n, sm.lut);
                     }
                 }
-                if (early_tail && wave == 3 && lane == 0)   // same-wave LDS ops complete in order
-                    st_granule(&p.tile_tail[cur], kValid | (uint64_t)extract_tail(st, T));
+                if (early_tail && wave == kDataWaves - 1 && lane == 0)   // same-wave LDS ops complete in order
+                    st_granule(&p.tile_tail[tix(p, cur)], kValid | (uint64_t)extract_tail(st, T));
             }
         }
         STAMP(5);
@@ -914,7 +952,7 @@ k_encode(EncodeParams p)
     const int wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     if (tid < 256) sm.lut[lut_slot((uint32_t)tid)] = p.lut[tid];
-    if (tid < 256) zero_words(&sm.stage[0][0], (uint32_t)kSlots * kStageWords / 4u, tid);
+    if (tid < kDataThreads) zero_words(&sm.stage[0][0], (uint32_t)kSlots * kStageWords / 4u, tid);
     if (tid == 0) { sm.abort_flag = 0u; sm.abort_snap = 0u; sm.n_resolved = 0u; sm.n_packed_pub = 0u; sm.n_res_snap = 0u; sm.bar = 0u; }
     if (tid < kSlots) { sm.ts[tid].bits = 0u; sm.ts[tid].flags = 0u; }
 
@@ -924,7 +962,7 @@ k_encode(EncodeParams p)
     if (c.b0 >= ntiles) return;
     c.my_tiles = (ntiles - c.b0 + c.G - 1) / c.G;
     __syncthreads();                                  // the only workgroup-wide barrier: LDS initialised
-    if (wave == 4) encode_scout_wave(p, sm, c, lane);
+    if (wave == kDataWaves) encode_scout_wave(p, sm, c, lane);
     else           encode_data_waves(p, sm, c, tid, lane, wave);
 }
 
@@ -1006,7 +1044,7 @@ __global__ void __launch_bounds__(kThreads) k_exclusive_scan(const uint32_t* in,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) s_abort = 0u;
     for (uint64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
-        const uint64_t base = tile * (uint64_t)kTileWords + (uint64_t)tid * 16u;
+        const uint64_t base = tile * (uint64_t)kScanTile + (uint64_t)tid * 16u;
         uint32_t v[16];
         uint64_t sum = 0;
 #pragma unroll
