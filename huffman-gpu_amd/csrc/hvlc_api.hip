@@ -56,20 +56,21 @@ constexpr uint64_t kHeaderBytes = kLutBytes + kStatusBytes;
 
 inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
-// granule layout for `tiles` tiles: tile_bits | tile_tail | group_desc, each padded to 16 B
-// (the arrays are addressed transposed, kGranRows x tile_cols and kGranRowsG x group_cols: hvlc_device.hip.h)
-struct Layout { uint64_t tiles_pad, groups_pad, bytes; uint32_t tile_cols, group_cols; };
+// workspace behind the header, for an encoder call of `tiles` tiles (offsets in bytes):
+//   bits32 [round_up(tiles, 64)] | recs [tiles + 1] | group_desc [groups, padded to 8 + 8]
+// k_exclusive_scan reuses the same area as  tile_bits [tiles] | group_desc [groups]  (8 bytes each).
+struct Layout { uint64_t off_bits32, off_recs, off_groups, bytes, scan_off_groups, scan_bytes; };
 inline Layout layout_for(uint64_t tiles)
 {
     Layout l;
-    const uint64_t groups = (tiles + kGroupTiles - 1) / kGroupTiles + 1;
-    l.tile_cols  = (uint32_t)((tiles + kGranRows - 1) / kGranRows);
-    if (l.tile_cols < 1) l.tile_cols = 1;
-    l.group_cols = (uint32_t)((groups + kGranRowsG - 1) / kGranRowsG);
-    if (l.group_cols < 1) l.group_cols = 1;
-    l.tiles_pad  = (uint64_t)kGranRows * l.tile_cols;
-    l.groups_pad = (uint64_t)kGranRowsG * l.group_cols;
-    l.bytes      = (2 * l.tiles_pad + l.groups_pad) * 8;
+    const uint64_t groups = (tiles + kGroupTiles - 1) / kGroupTiles;
+    l.off_bits32 = 0;
+    l.off_recs   = round_up(round_up(tiles, kGroupTiles) * 4, 64);
+    l.off_groups = l.off_recs + round_up((tiles + 1) * sizeof(TileRec), 64);
+    l.bytes      = l.off_groups + (round_up(groups, 8) + 8) * 8;
+    l.scan_off_groups = round_up(tiles * 8, 64);
+    l.scan_bytes = l.scan_off_groups + (groups + 1) * 8;
+    if (l.bytes < l.scan_bytes) l.bytes = round_up(l.scan_bytes, 64);
     return l;
 }
 
@@ -90,15 +91,18 @@ inline uint32_t* ws_status(hvlc_ctx* c) { return (uint32_t*)(c->ws + kLutBytes);
 inline uint64_t* ws_result(hvlc_ctx* c) { return (uint64_t*)(c->ws + kLutBytes + 8); }
 inline uint8_t*  ws_gran(hvlc_ctx* c)   { return c->ws + kHeaderBytes; }
 
-void fill_granule_ptrs(hvlc_ctx* c, uint64_t tiles, EncodeParams& p)
+void fill_granule_ptrs(hvlc_ctx* c, uint64_t tiles, EncodeParams& p, bool scan)
 {
     const Layout l = layout_for(tiles);
-    uint64_t* g = (uint64_t*)ws_gran(c);
-    p.tile_bits  = g;
-    p.tile_tail  = g + l.tiles_pad;
-    p.group_desc = g + 2 * l.tiles_pad;
-    p.tile_cols  = l.tile_cols;
-    p.group_cols = l.group_cols;
+    uint8_t* g = ws_gran(c);
+    if (scan) {
+        p.tile_bits  = (uint64_t*)g;
+        p.group_desc = (uint64_t*)(g + l.scan_off_groups);
+    } else {
+        p.bits32     = (uint32_t*)(g + l.off_bits32);
+        p.recs       = (TileRec*)(g + l.off_recs);
+        p.group_desc = (uint64_t*)(g + l.off_groups);
+    }
     p.status     = ws_status(c);
     p.result     = ws_result(c);
     p.timeout_ticks = c->timeout_ticks;
@@ -263,7 +267,7 @@ int hvlc_encode(hvlc_ctx* c,
     p.num_segs = hvlc_num_segments(num_words);
     p.lut = ws_lut(c);  p.out = d_out_bits;  p.out_cap = out_capacity_words;
     p.offsets = d_out_offsets;  p.total_bits = d_total_bits;
-    fill_granule_ptrs(c, tiles, p);
+    fill_granule_ptrs(c, tiles, p, false);
 #ifdef HVLC_EXPERIMENT
     p.dbg = (uint32_t)env_int("HVLC_DBG", 0);
     p.dbg_buf = g_dbg_buf;
@@ -277,7 +281,7 @@ int hvlc_encode(hvlc_ctx* c,
     if (pgrid > 2048) pgrid = 2048;
     hipLaunchKernelGGL(k_prepare, dim3(pgrid), dim3(kThreads), 0, s,
                        d_codewords, d_codewordlens, ws_lut(c), ws_status(c), ws_result(c),
-                       (uint4*)ws_gran(c), vecs, d_out_bits, out_capacity_words, d_total_bits,
+                       (uint4*)ws_gran(c), vecs, l.off_recs / 16, d_out_bits, out_capacity_words, d_total_bits,
                        tiles == 0 ? 1 : 0);
     HVLC_HIP(c, hipGetLastError());
     if (tiles == 0) { c->last_grid = 0; return HVLC_OK; }
@@ -294,6 +298,9 @@ int hvlc_encode(hvlc_ctx* c,
     // the whole chip would run at their pace (measured: 2 groups/us whatever the tile size).  An odd grid
     // rotates that role over all workgroups.
     if (grid > 64 && (grid & 1u) == 0u) grid -= 1;
+    // a tile's offset comes from its group's LAST tile: a workgroup must never hold an earlier tile of the same
+    // 64-tile group in its ring while that last tile is still waiting for a ring slot
+    if (grid < tiles && grid < (uint64_t)kGroupTiles) return HVLC_ERR_ARG;
     c->last_grid = (int)grid;
     const bool prof = c->ev && c->ev_used < c->ev_cap;
     if (prof) HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used], s));
@@ -349,6 +356,7 @@ int hvlc_finish(hvlc_ctx* c, void* stream, uint64_t* total_bits)
     uint64_t bits;
     memcpy(&bits, &c->h_status[2], 8);
     if (total_bits) *total_bits = bits;
+    if (flags & kFlagLayout)   return HVLC_ERR_HIP;      // LDS layout assumption broken: a build problem, never data
     if (flags & kFlagTimeout)  return HVLC_ERR_TIMEOUT;
     if (flags & kFlagTable)    return HVLC_ERR_TABLE;
     if (flags & kFlagCapacity) return HVLC_ERR_CAPACITY;
@@ -429,9 +437,9 @@ int hvlc_exclusive_scan(hvlc_ctx* c, const uint32_t* d_counts, uint64_t n,
     EncodeParams p;
     memset(&p, 0, sizeof(p));
     p.num_tiles = tiles;
-    fill_granule_ptrs(c, tiles, p);
+    fill_granule_ptrs(c, tiles, p, true);
     const Layout l = layout_for(tiles);
-    HVLC_HIP(c, hipMemsetAsync(ws_gran(c), 0, l.bytes, s));
+    HVLC_HIP(c, hipMemsetAsync(ws_gran(c), 0, l.scan_bytes, s));
     HVLC_HIP(c, hipMemsetAsync(ws_status(c), 0, 16, s));
     static int scan_bpc = 0;
     if (!scan_bpc) scan_bpc = pick_blocks_per_cu(c, k_exclusive_scan, kThreads, 0, 4);

@@ -10,21 +10,26 @@
 // Decomposition (all names follow the reference's domain):
 //   segment  256 input words = 1024 symbols  = ONE WAVE-ROW (64 lanes x 16 bytes);
 //            the reference's block (main_test_cu.cu:43); unit of out_offsets
-//   tile     16 segments = 16 KiB            = one pass of a 256-thread workgroup;
-//            wave w owns the tile's segments 4w..4w+3 (4 KiB contiguous)
-//   group    64 tiles = 1 MiB                = unit of the second scan level
+//   tile     12 segments = 12 KiB            = one pass of a workgroup's 3 data waves;
+//            data wave w owns the tile's segments 4w..4w+3 (4 KiB contiguous)
+//   group    64 tiles = 768 KiB              = unit of the second scan level
 //
-// Per tile:  (1) coalesced dwordx4 loads; (2) per-lane LDS table lookups and
-// 64-bit codeword concatenation of 16 symbols; (3) wave64 DPP prefix scan of the
-// bit lengths per segment, wave totals through LDS; (4) the tile's bit count is
-// PUBLISHED (8-byte self-validating granule, relaxed agent-scope store);
-// (5) "pabio": each lane ORs its <=64 bits into an LDS staging buffer with <=3
-// ds_or_b32 at TILE-LOCAL bit positions (so packing does not wait for the global
-// offset); (6) wave 0 resolves the tile's global bit offset by a two-level
-// decoupled look-back (64 tile granules + 64 group granules per hop, all lanes of
-// the wave in parallel) and fetches the <=31 carry bits of the predecessor;
-// (7) the staging buffer is funnel-shifted (v_alignbit_b32) by offset%32 and
-// stored with coalesced dword stores; segment offsets are written as uint64.
+// Workgroup = 3 DATA waves + 1 SCOUT wave (one wave per SIMD).  Data waves, per
+// tile: (1) coalesced non-temporal dwordx4 loads (next tile prefetched);
+// (2) per-lane LDS table lookups and 64-bit concatenation of 16 symbols;
+// (3) wave64 DPP prefix scan of the bit lengths per segment, wave totals through
+// LDS; (4) the tile's bit count is PUBLISHED (8-byte self-validating granule,
+// relaxed agent-scope store); (5) "pabio": each lane ORs its <=64 bits into one
+// of kSlots LDS staging slots with <=3 ds_or_b32 at TILE-LOCAL bit positions (so
+// packing does not wait for the global offset); (7) once the scout has resolved
+// the tile, the slot is funnel-shifted (v_alignbit_b32) by offset%32 and stored
+// with coalesced dword stores; segment offsets are written as uint64.
+// Scout wave: (6) resolves every packed tile's global bit offset by a two-level
+// decoupled look-back (in-group tile granules; group leaders walk 64 group
+// granules per hop, other tiles wait for the previous group's inclusive prefix)
+// and fetches the <=31 carry bits of the predecessor; one Resolver per slot is in
+// flight.  The scout exists because VMEM retires in order per wave: a data wave
+// polling granules would drain its own prefetch and stores first.
 //
 // Forward progress: the grid is PERSISTENT and sized to be co-resident (host side,
 // hvlc_api.hip); tile t is processed by workgroup t % gridDim.x, tiles of one
@@ -66,14 +71,20 @@ constexpr int      kStageWords  = (int)(kFastBits / 32u) + 16;             // ca
 #endif
 constexpr int      kSlots       = HVLC_SLOTS;                       // staging slots (packed tiles in flight) per workgroup
 constexpr uint32_t kPollAge     = 1;                       // a tile's granules are requested once this many newer tiles are packed
-constexpr int      kGranRows    = 256;                     // rows of the transposed granule layout (tiles); groups use 64
-constexpr int      kGranRowsG   = 64;
 constexpr uint64_t kValid       = 1ull << 63;
 constexpr uint64_t kStAgg       = 1ull << 62;              // group granule: aggregate of the group
 constexpr uint64_t kStPre       = 2ull << 62;              // group granule: inclusive prefix through the group
 constexpr uint64_t kValMask     = (1ull << 62) - 1;
 
-enum : uint32_t { kFlagTable = 1u, kFlagCapacity = 2u, kFlagTimeout = 4u };
+// What a tile waits for, in one 16-byte record polled with ONE scalar load:
+//   P    = kValid | global exclusive bit offset of the tile, written by the LAST tile of the tile's
+//          group (the group leader) for all tiles of the group at once;
+//   tail = kValid32 | the last 31 bits of the stream before the tile, written by the tile before it
+//          (record 0: preset by k_prepare).
+struct alignas(16) TileRec { uint64_t P; uint32_t tail; uint32_t pad; };
+constexpr uint32_t kValid32 = 1u << 31;
+
+enum : uint32_t { kFlagTable = 1u, kFlagCapacity = 2u, kFlagTimeout = 4u, kFlagLayout = 8u };
 
 struct EncodeParams {
     const uint4*    in;          // input words, 16-byte aligned
@@ -88,11 +99,10 @@ struct EncodeParams {
     uint64_t*       total_bits;  // user's device word (nullable)
     uint64_t*       result;      // workspace: [0] total bits
     uint32_t*       status;      // workspace: flag word
-    uint64_t*       tile_bits;   // granule per tile: kValid | bits
-    uint64_t*       tile_tail;   // granule per tile: kValid | last 31 bits of the stream through this tile
-    uint64_t*       group_desc;  // granule per group: status | value
-    uint32_t        tile_cols;   // granule arrays are stored TRANSPOSED: tile t at (t % kGranRows) * tile_cols + t / kGranRows,
-    uint32_t        group_cols;  // so that the granules of consecutive tiles lie kilobytes apart (different memory channels)
+    uint32_t*       bits32;      // encoder: word per tile, kValid32 | bits of the tile (group g = words 64g..64g+63)
+    TileRec*        recs;        // encoder: record per tile (+1), see TileRec
+    uint64_t*       group_desc;  // granule per group: status | value (encoder and scan)
+    uint64_t*       tile_bits;   // scan kernel only: granule per scan tile, kValid | sum
     uint64_t        timeout_ticks;   // s_memrealtime ticks (100 MHz)
     uint32_t        dbg;             // ablation flags, honoured only in -DHVLC_EXPERIMENT builds (tools/)
     uint64_t*       dbg_buf;         // phase stamps [grid][2][16], -DHVLC_EXPERIMENT builds only
@@ -137,19 +147,8 @@ struct Stamps {
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
-// Granule addressing.  Consecutive tiles are resolved by workgroups all over the chip at about the same
-// time; with a linear array their 8-byte granules share 64-byte lines and one memory channel, and the
-// stores and polls of the active window serialise there (measured: ~120 tiles/us chip-wide whatever the
-// tile size).  The transposed layout puts consecutive tiles tile_cols * 8 bytes apart.
-__device__ __forceinline__ uint64_t tix(const EncodeParams& p, uint64_t t)
-{
-    return (t & (uint64_t)(kGranRows - 1)) * p.tile_cols + (t / kGranRows);
-}
-__device__ __forceinline__ uint64_t gix(const EncodeParams& p, uint64_t g)
-{
-    return (g & (uint64_t)(kGranRowsG - 1)) * p.group_cols + (g / kGranRowsG);
-}
-
+// Inter-workgroup words: written once per launch with ONE relaxed agent-scope (sc1, write-through) store,
+// zeroed by k_prepare before every launch, each carrying its own valid bit ("the data is the flag").
 __device__ __forceinline__ uint64_t ld_granule(const uint64_t* p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -158,6 +157,41 @@ __device__ __forceinline__ void st_granule(uint64_t* p, uint64_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void st_word(uint32_t* p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One polling round of the scout: ONE vector sc1 load instruction fetches the 16-byte records of up to three
+// tiles (lanes 0-11, a dword each) and, for a group leader, 8 group granules (lanes 16-31); the values are
+// moved to SGPRs (v_readlane) so that everything the scout decides is scalar code.
+// (Polling through the scalar memory path -- s_load ... glc -- was measured too: half the hand-off latency
+// with two pollers (tools/ubench.hip), but with 1535 scouts polling the scalar caches serialise their misses
+// and the kernel ran 15x slower.)
+typedef uint32_t u32x4  __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+
+template <bool WINDOW>
+__device__ __forceinline__ void poll_round(const void* const (&a)[3], u32x4 (&r)[3], const void* w, u32x16& x, int lane)
+{
+    const uint32_t* src = (const uint32_t*)a[0];
+    if (lane >= 4)  src = (const uint32_t*)a[1];
+    if (lane >= 8)  src = (const uint32_t*)a[2];
+    if (lane >= 16) src = (const uint32_t*)w - 16 + 4;            // lane 16 -> w[0] (see the index below)
+    const int idx = lane < 16 ? (lane & 3) : lane - 4;             // lanes 16..31: (w - 12)[lane - 4] = w[lane - 16]
+    uint32_t v = 0;
+    if (lane < 12 || (WINDOW && lane >= 16 && lane < 32))
+        v = __hip_atomic_load(src + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[s][k] = (uint32_t)__builtin_amdgcn_readlane((int)v, 4 * s + k);
+    if (WINDOW) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = (uint32_t)__builtin_amdgcn_readlane((int)v, 16 + k);
+    }
+}
+
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
 {
     (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -263,6 +297,35 @@ __device__ __forceinline__ uint32_t extract_tail(const uint32_t* st, uint32_t e)
 __device__ __forceinline__ uint32_t lut_slot(uint32_t s) { return s ^ (s >> 4); }
 __device__ __forceinline__ uint32_t hash4(uint32_t w) { return w ^ ((w >> 4) & 0x0f0f0f0fu); }
 
+// LDS byte offset (slot * 8) of byte B of the hashed word h in ONE VALU op: SDWA selects the byte,
+// the shift scales it to the 8-byte table entries.
+template <int B>
+__device__ __forceinline__ uint32_t slot_offset(uint32_t h)
+{
+    uint32_t off;
+    const uint32_t three = 3u;
+    if (B == 3)      asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "s"(three), "v"(h));
+    else if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "s"(three), "v"(h));
+    else if (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "s"(three), "v"(h));
+    else             asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "s"(three), "v"(h));
+    return off;
+}
+// The table is the FIRST member of the workgroup's only LDS object, i.e. it sits at LDS address 0
+// (checked once per launch in k_encode): the slot offset is the whole ds_read_b64 address.
+__device__ __forceinline__ uint2 lut_at(const uint2* /*lut*/, uint32_t byte_off)
+{
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const u32x2 lds_u32x2;
+    const u32x2 e = *reinterpret_cast<lds_u32x2*>((uintptr_t)byte_off);
+    return make_uint2(e.x, e.y);
+}
+#define HVLC_SYM(B)                                              \
+    {                                                            \
+        const uint2 e = lut_at(lut, slot_offset<B>(h));          \
+        acc = (acc << e.y) | e.x;                                \
+        tot += e.y;                                              \
+    }
+
 template <bool FULL>
 __device__ __forceinline__ void encode16(const uint4& v, int nvalid, const uint2* lut,
                                          uint64_t& acc, uint32_t& tot)
@@ -272,14 +335,11 @@ __device__ __forceinline__ void encode16(const uint4& v, int nvalid, const uint2
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!FULL && k >= nvalid) break;
-#pragma unroll
-        for (int b = 3; b >= 0; --b) {
-            const uint2 e = lut[(w[k] >> (8 * b)) & 255u];
-            acc = (acc << e.y) | e.x;
-            tot += e.y;
-        }
+        const uint32_t h = w[k];
+        HVLC_SYM(3) HVLC_SYM(2) HVLC_SYM(1) HVLC_SYM(0)
     }
 }
+#undef HVLC_SYM
 
 // A lane-row whose 16 codewords exceed 64 bits (lengths up to 31 allow 496): two symbols (<=62 bits)
 // per put_bits64.  Rare with real tables, so it runs as a divergent branch of the fast path.
@@ -334,30 +394,16 @@ struct DataBarrier {
     {
         target += (uint32_t)kDataWaves;
         if (lane == 0) (void)__hip_atomic_fetch_add(&sm.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(&sm.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) { }
+        while (__hip_atomic_load(&sm.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+            __builtin_amdgcn_s_sleep(1);                  // a spinning wave must not take issue slots from the working ones
     }
 };
 
-// Granule values a look-back has in flight (wave 0 only).  Issued one iteration before they are
-// consumed, so the round trip to the other XCDs' writes overlaps the next tile's encode.
+// Granule values a look-back may bring along (k_exclusive_scan passes none).
 struct LbRegs {
     uint64_t d = 0;     // tile_bits of predecessor tile-1-lane (inside the group)
     uint64_t v = 0;     // group_desc of group g-1-lane
-    uint64_t t = 0;     // tile_tail of tile-1 (lane 0)
 };
-
-__device__ __forceinline__ void lookback_issue(const EncodeParams& p, uint64_t tile, int lane, LbRegs& L)
-{
-    const uint32_t r = (uint32_t)(tile & (kGroupTiles - 1));
-    const int64_t  gi = (int64_t)(tile / kGroupTiles) - 1 - lane;
-    const bool leader = (r == kGroupTiles - 1) || (tile == p.num_tiles - 1);
-    if (HVLC_DBG(p, kDbgNoLookback)) return;
-    L.d = (uint32_t)lane < r ? ld_granule(p.tile_bits + tix(p, tile - 1 - (uint64_t)lane)) : 0ull;
-    // only a group's last tile walks the 64-group window; everybody else waits for the previous group's
-    // inclusive prefix (one granule): thousands of scouts polling the same few lines was the rate limit
-    L.v = (gi >= 0 && (leader || lane == 0)) ? ld_granule(&p.group_desc[gix(p, (uint64_t)gi)]) : 0ull;
-    L.t = (lane == 0 && tile > 0) ? ld_granule(&p.tile_tail[tix(p, tile - 1)]) : 0ull;
-}
 
 // Two-level decoupled look-back, executed by ONE wave with all 64 lanes active.
 // Level 1: lanes 0..r-1 read the bit counts of the r predecessors inside the tile's group.
@@ -365,8 +411,8 @@ __device__ __forceinline__ void lookback_issue(const EncodeParams& p, uint64_t t
 //          plus the aggregates after it give the group's exclusive prefix.  The last tile of a
 //          group (the "leader") publishes the group's aggregate as soon as level 1 is done and its
 //          inclusive prefix after level 2, so one hop covers 64 tiles / 64 groups.
-// `L` may carry values loaded earlier by lookback_issue (or zeros: everything is polled here).
-template <bool WIDE, bool TAIL>
+// `L` may carry values loaded earlier (or zeros: everything is polled here).
+template <bool WIDE>
 __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, uint64_t T, int lane, LbRegs L,
                                          uint64_t& P_out, uint32_t& pred_tail)
 {
@@ -417,114 +463,11 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
     const uint64_t P = excl + insum;
     if (leader && lane == 0) st_granule(&p.group_desc[g], kStPre | ((P + T) & kValMask));
 
-    uint32_t pt = 0;
-    if (TAIL && tile > 0) {
-        uint64_t t = L.t;
-        for (;;) {
-            if (!__any(lane == 0 && !(t >> 63))) break;
-            if (lane == 0 && !(t >> 63)) t = ld_granule(&p.tile_tail[tile - 1]);
-            if (!__any(lane == 0 && !(t >> 63))) break;
-            if (!spin.wait(p)) return false;
-        }
-        pt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t) & 0x7fffffffu;
-    }
+    const uint32_t pt = 0;
     P_out = P;
     pred_tail = pt;
     return true;
 }
-
-// One look-back in progress in the scout wave, split so that a round of the scout can EVALUATE every
-// look-back in flight first (eval: no memory operation on the common path) and only then REQUEST what
-// is still missing for all of them (repoll): vector-memory operations retire in order per wave, so a
-// load issued between two evaluations would put a full round trip in front of the second one.
-// A group leader (last tile of its group) publishes the group's aggregate as soon as its in-group
-// predecessors are known and the group's inclusive prefix as soon as the group window is resolved:
-// both are on every later tile's critical path.
-struct Resolver {
-    LbRegs   L;
-    uint64_t insum = 0;
-    uint32_t n = 0;             // workgroup-local tile number
-    bool     active = false;
-    bool     ga_done = false;
-    bool     miss_d = false, miss_v = false, miss_t = false;   // per lane: what the last eval() found missing
-
-    __device__ __forceinline__ void start(const EncodeParams& p, uint32_t n_, uint64_t tile, int lane)
-    {
-        n = n_; active = true; ga_done = false; insum = 0;
-        lookback_issue(p, tile, lane, L);
-    }
-
-    // 1 = resolved (P / pred_tail valid), 0 = something is missing (call repoll, evaluate again next round),
-    // -1 = timed out (only the rare extended-window path can wait)
-    __device__ __forceinline__ int eval(const EncodeParams& p, uint64_t tile, uint32_t T, int lane,
-                                        uint64_t& P_out, uint32_t& pred_tail)
-    {
-        if (HVLC_DBG(p, kDbgNoLookback)) { P_out = tile * 36400ull; pred_tail = 0; active = false; return 1; }
-        const uint32_t r = (uint32_t)(tile & (kGroupTiles - 1));
-        const uint64_t g = tile / kGroupTiles;
-        const bool leader = (r == kGroupTiles - 1) || (tile == p.num_tiles - 1);
-        const bool need = (uint32_t)lane < r;
-        const int64_t gi = (int64_t)g - 1 - lane;
-        const uint64_t v = gi < 0 ? kStPre : L.v;                   // before the stream: inclusive prefix 0
-        int fp;
-        if (leader) {
-            // the nearest inclusive prefix in the window plus the aggregates after it
-            const uint64_t pm  = __ballot((v >> 62) == 2);
-            fp = pm ? __builtin_ctzll(pm) : 64;
-            const uint64_t xm  = __ballot((v >> 62) == 0);
-            const uint64_t low = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
-            miss_v = ((xm & low) >> lane) & 1ull;
-        } else {
-            // the previous group's inclusive prefix, published by that group's last tile
-            fp = 0;
-            miss_v = (lane == 0) && (v >> 62) != 2;
-        }
-        miss_d = need && !(L.d >> 63);
-        miss_t = (lane == 0 && tile > 0) && !(L.t >> 63);
-        if (!ga_done && !__any(miss_d)) {
-            insum = (uint64_t)wave_sum_u32(need ? (uint32_t)L.d : 0u);
-            if (leader && lane == 0) st_granule(&p.group_desc[gix(p, g)], kStAgg | (insum + T));
-            TL(p, tile, 3, leader && lane == 0);
-            TL(p, tile, 2, !leader && lane == 0);
-            ga_done = true;
-        }
-        if (__any(miss_d || miss_v || miss_t)) return 0;
-        uint64_t excl = wave_sum_u64(lane <= fp ? (v & kValMask) : 0ull);
-        if (fp == 64) {                                             // no prefix in the nearest 64 groups (rare): keep going
-            Spin spin;
-            for (int64_t gb = (int64_t)g - 64; gb > 0; gb -= 64) {
-                const int64_t gj = gb - 1 - lane;
-                uint64_t u = gj < 0 ? kStPre : 0ull;
-                int fq;
-                for (;;) {
-                    if (gj >= 0 && (u >> 62) == 0) u = ld_granule(&p.group_desc[gix(p, (uint64_t)gj)]);
-                    const uint64_t pm2  = __ballot((u >> 62) == 2);
-                    fq = pm2 ? __builtin_ctzll(pm2) : 64;
-                    const uint64_t xm2  = __ballot((u >> 62) == 0);
-                    const uint64_t low2 = fq >= 63 ? ~0ull : ((2ull << fq) - 1ull);
-                    if ((xm2 & low2) == 0) break;
-                    if (!spin.wait(p)) return -1;
-                }
-                excl += wave_sum_u64(lane <= fq ? (u & kValMask) : 0ull);
-                if (fq < 64) break;
-            }
-        }
-        const uint64_t P = excl + insum;
-        if (leader && lane == 0) st_granule(&p.group_desc[gix(p, g)], kStPre | (P + T));
-        P_out = P;
-        pred_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.t) & 0x7fffffffu;
-        active = false;
-        return 1;
-    }
-
-    __device__ __forceinline__ void repoll(const EncodeParams& p, uint64_t tile, int lane)
-    {
-        const int64_t gi = (int64_t)(tile / kGroupTiles) - 1 - lane;
-        if (miss_d) L.d = ld_granule(p.tile_bits + tix(p, tile - 1 - (uint64_t)lane));
-        if (miss_v) L.v = ld_granule(&p.group_desc[gix(p, (uint64_t)gi)]);
-        if (miss_t) L.t = ld_granule(&p.tile_tail[tix(p, tile - 1)]);
-    }
-};
 
 // Funnel-shift the staging buffer by s = (global bit offset % 32) and store `nown` finished words
 // at out[ow..].  sb[0] is the carry slot (low s bits = last s bits of the preceding stream).
@@ -605,7 +548,7 @@ __device__ __forceinline__ void finish_tile(const EncodeParams& p, Smem& sm, uin
     if (!(ts.flags & kTsEarlyTail) && tid == 0) {
         const uint32_t own  = extract_tail(sb + 1, T);
         const uint32_t tail = T >= 31u ? own : (((ts.pred_tail << T) | own) & 0x7fffffffu);
-        st_granule(&p.tile_tail[tix(p, tile)], kValid | (uint64_t)tail);
+        st_word(&p.recs[tile + 1].tail, kValid32 | tail);
     }
 }
 
@@ -669,7 +612,7 @@ __device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, Da
         Pq += Tq;
     }
     bar.sync(sm, lane);
-    if (tid == 0) st_granule(&p.tile_tail[tix(p, tile)], kValid | (uint64_t)carry);
+    if (tid == 0) st_word(&p.recs[tile + 1].tail, kValid32 | carry);
     zero_words(big, 2u * kStageWords / 4u, tid);
 }
 
@@ -750,7 +693,7 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
             slow = T > kFastBits;                         // fits no staging slot: general path, once the ring is empty
             const bool early_tail = !slow && clast >= 31u;   // the tile's last 31 bits are all written by the last data wave
             if (tid == 0) {
-                st_granule(&p.tile_bits[tix(p, cur)], kValid | (uint64_t)T);   // publish before anything else
+                st_word(&p.bits32[cur], kValid32 | T);               // publish before anything else
                 TL(p, cur, 0, true);
                 sm.ts[sp].bits  = T;
                 sm.ts[sp].flags = early_tail ? kTsEarlyTail : 0u;
@@ -780,7 +723,7 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
                     }
                 }
                 if (early_tail && wave == kDataWaves - 1 && lane == 0)   // same-wave LDS ops complete in order
-                    st_granule(&p.tile_tail[tix(p, cur)], kValid | (uint64_t)extract_tail(st, T));
+                    st_word(&p.recs[(uint64_t)cur + 1].tail, kValid32 | extract_tail(st, T));
             }
         }
         STAMP(5);
@@ -826,95 +769,163 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
 }
 
 // ------------------------------------------------------------------------------------------------
-// SCOUT wave (threads 256..319): all granule polling.  Vector-memory operations retire in order per
-// wave, so a data wave that polled granules would have to drain its HBM prefetch and its stores
-// first; the scout's only memory operations are the 8-byte relaxed agent-scope loads/stores that
-// cross XCDs (2-3 dependent round trips per tile).  It free-runs: it takes no part in the data waves'
-// barrier, resolves the workgroup's tiles in order (blocking, bounded) as soon as they are packed and
-// hands each result over through LDS (release store of n_resolved).
+// SCOUT wave: everything that crosses workgroups.  It is a SCALAR program: what a tile waits for is one
+// 16-byte record (TileRec), polled with one s_load per tile in flight, all of a round's loads in one asm
+// block (one round trip per round).  Vector-memory operations retire in order per wave and queue behind
+// the CU's streaming loads, so neither the data waves nor a vector poll loop should do this.
+//
+// Offsets come from a two-level scan over the granules: the LAST tile of every 64-tile group is the
+// group's leader.  Its scout (LeaderDuty) reads the 64 bit counts of the group (one vector load),
+// publishes the group's aggregate, walks the group granules downwards (8 per scalar load) to the nearest
+// inclusive prefix, publishes the group's inclusive prefix and then the global offset of EVERY tile of the
+// group (one 64-lane store into the records).  So a tile's offset costs its own scout one scalar poll, and
+// the chain packed -> leader -> records is three hand-offs whatever the input size.
+// The scout free-runs: it takes no part in the data waves' barrier and hands results over through LDS.
 // ------------------------------------------------------------------------------------------------
+static_assert(kSlots <= 3, "the scout polls at most three records per round");
+struct LeaderDuty {
+    bool     active = false, have_bits = false, win_done = false;
+    uint32_t g = 0, n = 0;      // group, tiles in it
+    uint32_t A = 0;             // aggregate of the group (64 tiles x < 2^22 bits)
+    uint64_t E = 0;             // exclusive prefix of the group, collected so far
+    int32_t  j = 0;             // next group granule to look at, walking down; -1: start of the stream
+    uint32_t excl_in = 0;       // per lane: bits of the group's tiles before tile 64g+lane
+};
+
 __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& sm, RingCtl c, int lane)
 {
-    STAMP_DECL;
-    Resolver res[kSlots];               // one look-back in flight per ring slot (static indexing: registers)
-    bool     done[kSlots], pend[kSlots];
+    bool     act[kSlots], done[kSlots];
+    uint32_t num[kSlots];               // workgroup-local number of the tile a slot holds
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) { done[s] = false; pend[s] = false; }
-    uint32_t n_started = 0, n_done = 0; // tiles whose look-back has been started / handed to the data waves
+    for (int s = 0; s < kSlots; ++s) { act[s] = false; done[s] = false; num[s] = 0; }
+    uint32_t n_started = 0, n_done = 0; // tiles whose record is being polled / handed to the data waves
+    uint32_t n_duty = 0;                // tiles already checked for the group-leader role
+    LeaderDuty d;
     uint32_t rounds = 0;
     uint64_t t_progress = 0;
+    const uint32_t last_tile = (uint32_t)p.num_tiles - 1u;
 
     while (n_done < c.my_tiles) {
         bool progress = false;
-        STAMP(0);
-        // (1) evaluate every look-back in flight on what the previous round requested: the first use waits
-        //     for all of this wave's outstanding loads at once, so a round costs ONE granule round trip
+
+        // (1) this round's requests: the leader's bit counts (vector, asynchronous), then the records of the
+        //     tiles in flight and, for a leader, 8 group granules, in one scalar block
+        uint32_t bv = kValid32;
+        if (d.active && !d.have_bits && (uint32_t)lane < d.n)
+            bv = __hip_atomic_load(&p.bits32[(uint64_t)d.g * kGroupTiles + (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const void* a[3];
+        u32x4 r[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            a[s] = &p.recs[(s < kSlots && act[s < kSlots ? s : 0]) ? (uint64_t)c.tile(num[s < kSlots ? s : 0]) : 0ull];
+        if (d.active && !d.win_done) {
+            const int32_t c0 = d.j & ~7;
+            u32x16 w;
+            poll_round<true>(a, r, p.group_desc + c0, w, lane);
+            bool stop = false;
+#pragma unroll
+            for (int i = 7; i >= 0; --i) {
+                if (!stop && c0 + i <= d.j) {
+                    const uint64_t v  = ((uint64_t)w[2 * i + 1] << 32) | (uint64_t)w[2 * i];
+                    const uint32_t st = (uint32_t)(v >> 62);
+                    if (st == 0u) stop = true;                            // not published yet: again next round
+                    else {
+                        d.E += v & kValMask;
+                        d.j  = c0 + i - 1;
+                        progress = true;
+                        if (st == 2u) { d.win_done = true; stop = true; }  // an inclusive prefix ends the walk
+                    }
+                }
+            }
+            if (!d.win_done && d.j < 0) d.win_done = true;                // walked down to the start of the stream
+        } else {
+            u32x16 unused;
+            poll_round<false>(a, r, nullptr, unused, lane);
+        }
+
+        // (2) the tiles in flight: resolved when the leader's offset and the predecessor's tail are both there
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
-            pend[s] = false;
-            if (res[s].active) {
-                uint64_t P = 0; uint32_t pt = 0;
-                const uint32_t tile = c.tile(res[s].n);
-                const int rc = res[s].eval(p, tile, sm.ts[s].bits, lane, P, pt);
-                STAMP_COUNT(10, 1);
-#ifdef HVLC_EXPERIMENT
-                if (p.dbg_tl && lane == 0) p.dbg_tl[(uint64_t)tile * 8 + 6] += 1;
-#endif
-                if (rc < 0) {
-                    if (lane == 0) __hip_atomic_store(&sm.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    return;
-                }
-                if (rc > 0) {
-                    TL(p, tile, 4, lane == 0);
-                    if (lane == 0) { sm.ts[s].prefix = P; sm.ts[s].pred_tail = pt; sm.stage[s][0] = pt; }
+            if (act[s] && !done[s]) {
+                uint64_t P  = ((uint64_t)r[s].y << 32) | (uint64_t)r[s].x;
+                uint32_t tl = r[s].z;
+                if (HVLC_DBG(p, kDbgNoLookback)) { P = kValid | ((uint64_t)c.tile(num[s]) * 36400ull); tl = kValid32; }
+                if ((P >> 63) != 0ull && (tl >> 31) != 0u) {
+                    if (lane == 0) {
+                        sm.ts[s].prefix    = P & kValMask;
+                        sm.ts[s].pred_tail = tl & 0x7fffffffu;
+                        sm.stage[s][0]     = tl & 0x7fffffffu;
+                    }
                     done[s] = true;
                     progress = true;
-                } else {
-                    pend[s] = true;
-                    STAMP_COUNT(11, __any(res[s].miss_d) ? 1 : 0); STAMP_COUNT(12, __any(res[s].miss_v) ? 1 : 0);
-                    STAMP_COUNT(13, __any(res[s].miss_t) ? 1 : 0);
                 }
             }
         }
-        STAMP(1);
-        // (2) hand the resolved tiles over in order
+        // hand the resolved tiles over in order
         uint32_t nd = n_done;
 #pragma unroll
         for (int k = 0; k < kSlots; ++k) {
             const uint32_t sl = nd % kSlots;
-            bool d = false;
+            bool dn = false;
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) if ((uint32_t)s == sl) d = done[s];
-            if (nd < n_started && d) {
+            for (int s = 0; s < kSlots; ++s) if ((uint32_t)s == sl) dn = done[s] && act[s];
+            if (nd < n_started && dn) {
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) if ((uint32_t)s == sl) done[s] = false;
+                for (int s = 0; s < kSlots; ++s) if ((uint32_t)s == sl) { done[s] = false; act[s] = false; }
                 ++nd;
             }
         }
         if (nd != n_done) {
             n_done = nd;
             if (lane == 0) __hip_atomic_store(&sm.n_resolved, n_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            STAMP_COUNT(8, 1);
         }
-        // (3) all requests of this round, back to back: what is still missing, and the granules of newly packed tiles
-#pragma unroll
-        for (int s = 0; s < kSlots; ++s)
-            if (pend[s]) res[s].repoll(p, c.tile(res[s].n), lane);
+
+        // (3) the leader's duty
+        if (d.active && !d.have_bits) {
+            if (__ballot((bv >> 31) != 0u) == ~0ull) {
+                const uint32_t b    = (uint32_t)lane < d.n ? (bv & 0x7fffffffu) : 0u;
+                const uint32_t incl = wave_incl_scan(b);
+                d.excl_in   = incl - b;
+                d.A         = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                d.have_bits = true;
+                progress    = true;
+                if (lane == 0 && !d.win_done) st_granule(&p.group_desc[d.g], kStAgg | (uint64_t)d.A);
+            }
+        }
+        if (d.active && d.have_bits && d.win_done) {
+            if (lane == 0) st_granule(&p.group_desc[d.g], kStPre | (d.E + (uint64_t)d.A));   // later leaders wait for this
+            if ((uint32_t)lane < d.n)
+                st_granule(&p.recs[(uint64_t)d.g * kGroupTiles + (uint32_t)lane].P, kValid | (d.E + (uint64_t)d.excl_in));
+            d.active = false;
+            progress = true;
+        }
+
+        // (4) newly packed tiles: start polling their records; the last tile of a group starts that group's duty
         const uint32_t np = __hip_atomic_load(&sm.n_packed_pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         while (n_started < np && n_started - n_done < (uint32_t)kSlots) {
             const uint32_t sl = n_started % kSlots;
 #pragma unroll
             for (int s = 0; s < kSlots; ++s)
-                if ((uint32_t)s == sl) { res[s].start(p, n_started, c.tile(n_started), lane); done[s] = false; TL(p, c.tile(n_started), 1, lane == 0); }
+                if ((uint32_t)s == sl) { act[s] = true; done[s] = false; num[s] = n_started; }
             ++n_started;
             progress = true;
         }
-        STAMP_COUNT(9, 1);
+        while (!d.active && n_duty < n_started && !HVLC_DBG(p, kDbgNoLookback)) {
+            const uint32_t t = c.tile(n_duty);
+            ++n_duty;
+            if ((t & (uint32_t)(kGroupTiles - 1)) == (uint32_t)(kGroupTiles - 1) || t == last_tile) {
+                d.active = true; d.have_bits = false;
+                d.g = t / kGroupTiles; d.n = (t & (uint32_t)(kGroupTiles - 1)) + 1u;
+                d.E = 0; d.j = (int32_t)d.g - 1; d.win_done = (d.g == 0u);
+                progress = true;
+            }
+        }
+
         if (__hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
-        // watchdog: nothing resolved or started for timeout_ticks -> give up (and make every other workgroup give up)
+        // watchdog: nothing moved for timeout_ticks -> give up (and make every other workgroup give up)
         if (progress) { rounds = 0; t_progress = 0; }
         else {
-            if (n_started == n_done) __builtin_amdgcn_s_sleep(4);     // nothing in flight: wait for the data waves
+            if (n_started == n_done && !d.active) __builtin_amdgcn_s_sleep(4);   // nothing in flight: wait for the data waves
             if ((++rounds & 255u) == 0u) {
                 const uint64_t now = __builtin_amdgcn_s_memrealtime();
                 const uint32_t st  = atomicOr(p.status, 0u);  // RMW: coherent with the other workgroups' atomicOr
@@ -926,9 +937,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
                 }
             }
         }
-        STAMP(2);
     }
-    STAMP_DUMP(p.dbg_buf, 1, lane == 0);
 }
 
 // The persistent, ring-pipelined encoder.  A workgroup = 4 DATA waves + 1 SCOUT wave.  It owns tiles
@@ -951,6 +960,12 @@ k_encode(EncodeParams p)
     const int lane  = tid & 63;
     const int wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    // lut_at() addresses the table absolutely: the workgroup's LDS object must start at LDS address 0
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    if ((uint32_t)reinterpret_cast<uintptr_t>((lds_byte*)hvlc_smem_raw) != 0u) {
+        if (tid == 0) atomicOr(p.status, kFlagLayout);
+        return;
+    }
     if (tid < 256) sm.lut[lut_slot((uint32_t)tid)] = p.lut[tid];
     if (tid < kDataThreads) zero_words(&sm.stage[0][0], (uint32_t)kSlots * kStageWords / 4u, tid);
     if (tid == 0) { sm.abort_flag = 0u; sm.abort_snap = 0u; sm.n_resolved = 0u; sm.n_packed_pub = 0u; sm.n_res_snap = 0u; sm.bar = 0u; }
@@ -973,7 +988,7 @@ k_encode(EncodeParams p)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) k_prepare(const uint32_t* cw, const uint32_t* cl, uint2* lut,
                                                       uint32_t* status, uint64_t* result,
-                                                      uint4* granules, uint64_t granule_vecs,
+                                                      uint4* granules, uint64_t granule_vecs, uint64_t rec0_vec,
                                                       uint32_t* out_if_empty, uint64_t out_cap,
                                                       uint64_t* total_if_empty, int empty)
 {
@@ -999,7 +1014,7 @@ __global__ void __launch_bounds__(kThreads) k_prepare(const uint32_t* cw, const 
         }
     }
     for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < granule_vecs; i += (uint64_t)gridDim.x * kThreads)
-        granules[i] = make_uint4(0, 0, 0, 0);
+        granules[i] = i == rec0_vec ? make_uint4(0, 0, kValid32, 0) : make_uint4(0, 0, 0, 0);   // nothing precedes tile 0
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1063,7 +1078,7 @@ __global__ void __launch_bounds__(kThreads) k_exclusive_scan(const uint32_t* in,
         if (tid == 0) st_granule(&p.tile_bits[tile], kValid | (T & kValMask));
         if (wave == 0) {
             uint64_t P = 0; uint32_t unused = 0;
-            const bool ok = lookback<true, false>(p, tile, T, lane, LbRegs(), P, unused);
+            const bool ok = lookback<true>(p, tile, T, lane, LbRegs(), P, unused);
             if (lane == 0) { s_prefix = P; if (!ok) s_abort = 1u; }
         }
         __syncthreads();
