@@ -57,15 +57,16 @@ constexpr uint64_t kHeaderBytes = kLutBytes + kStatusBytes;
 inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
 // workspace behind the header, for an encoder call of `tiles` tiles (offsets in bytes):
-//   bits32 [round_up(tiles, 64)] | recs [tiles + 1] | group_desc [groups, padded to 8 + 8]
+//   tickets [8 x 128 B] | bits32 [round_up(tiles, 64)] | recs [tiles + 1] | group_desc [groups, padded to 8 + 8]
 // k_exclusive_scan reuses the same area as  tile_bits [tiles] | group_desc [groups]  (8 bytes each).
-struct Layout { uint64_t off_bits32, off_recs, off_groups, bytes, scan_off_groups, scan_bytes; };
+struct Layout { uint64_t off_tickets, off_bits32, off_recs, off_groups, bytes, scan_off_groups, scan_bytes; };
 inline Layout layout_for(uint64_t tiles)
 {
     Layout l;
     const uint64_t groups = (tiles + kGroupTiles - 1) / kGroupTiles;
-    l.off_bits32 = 0;
-    l.off_recs   = round_up(round_up(tiles, kGroupTiles) * 4, 64);
+    l.off_tickets = 0;
+    l.off_bits32 = (uint64_t)kTicketClasses * kTicketStride * 4;
+    l.off_recs   = l.off_bits32 + round_up(round_up(tiles, kGroupTiles) * 4, 64);
     l.off_groups = l.off_recs + round_up((tiles + 1) * sizeof(TileRec), 64);
     l.bytes      = l.off_groups + (round_up(groups, 8) + 8) * 8;
     l.scan_off_groups = round_up(tiles * 8, 64);
@@ -99,6 +100,7 @@ void fill_granule_ptrs(hvlc_ctx* c, uint64_t tiles, EncodeParams& p, bool scan)
         p.tile_bits  = (uint64_t*)g;
         p.group_desc = (uint64_t*)(g + l.scan_off_groups);
     } else {
+        p.tickets    = (uint32_t*)(g + l.off_tickets);
         p.bits32     = (uint32_t*)(g + l.off_bits32);
         p.recs       = (TileRec*)(g + l.off_recs);
         p.group_desc = (uint64_t*)(g + l.off_groups);
@@ -268,6 +270,9 @@ int hvlc_encode(hvlc_ctx* c,
     p.lut = ws_lut(c);  p.out = d_out_bits;  p.out_cap = out_capacity_words;
     p.offsets = d_out_offsets;  p.total_bits = d_total_bits;
     fill_granule_ptrs(c, tiles, p, false);
+    // TEST HOOK (tests/test_encode_gpu.py::test_timeout_is_reported_not_a_hang): the named tile never publishes its
+    // bit count, so every later tile waits for ever -- the bounded waits must turn that into HVLC_ERR_TIMEOUT
+    p.stall_tile = (uint32_t)env_int("HVLC_TEST_STALL_TILE", -1);
 #ifdef HVLC_EXPERIMENT
     p.dbg = (uint32_t)env_int("HVLC_DBG", 0);
     p.dbg_buf = g_dbg_buf;
@@ -287,20 +292,13 @@ int hvlc_encode(hvlc_ctx* c,
     if (tiles == 0) { c->last_grid = 0; return HVLC_OK; }
 
     uint64_t grid = (uint64_t)c->cus * (uint64_t)c->blocks_per_cu;
-    // TEST HOOK (tests/test_encode_gpu.py::test_timeout_is_reported_not_a_hang): an over-subscribed grid is not
-    // co-resident, so the bounded waits must turn the would-be deadlock into HVLC_ERR_TIMEOUT
+    // TEST HOOK (tests/test_encode_gpu.py::test_oversubscribed_grid_still_encodes): tiles are drawn by running
+    // workgroups only, so even a grid that is not co-resident must finish with the exact stream
     const int forced_grid = env_int("HVLC_TEST_FORCE_GRID", 0);
     if (forced_grid > 0) grid = (uint64_t)forced_grid;
     if (grid > tiles) grid = tiles;
-    // Tile t belongs to workgroup t % grid and the LAST tile of every 64-tile group does that group's share of
-    // the look-back (it waits for all 63 predecessors and publishes the aggregate / prefix everybody else
-    // needs).  With a grid that is a multiple of 64 the same grid/64 workgroups would own every such tile and
-    // the whole chip would run at their pace (measured: 2 groups/us whatever the tile size).  An odd grid
-    // rotates that role over all workgroups.
-    if (grid > 64 && (grid & 1u) == 0u) grid -= 1;
-    // a tile's offset comes from its group's LAST tile: a workgroup must never hold an earlier tile of the same
-    // 64-tile group in its ring while that last tile is still waiting for a ring slot
-    if (grid < tiles && grid < (uint64_t)kGroupTiles) return HVLC_ERR_ARG;
+    // every ticket class (block index % kTicketClasses) needs a workgroup to draw its tiles
+    if (grid < tiles && grid < (uint64_t)kTicketClasses) return HVLC_ERR_ARG;
     c->last_grid = (int)grid;
     const bool prof = c->ev && c->ev_used < c->ev_cap;
     if (prof) HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used], s));

@@ -64,13 +64,25 @@ constexpr int      kSegWords    = 256;
 constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 12: wave w owns segments 4w..4w+3
 constexpr int      kGroupTiles  = 64;
 constexpr int      kScanTile    = 4096;                    // elements per workgroup pass of k_exclusive_scan
-constexpr uint32_t kFastBits    = (uint32_t)kDataThreads * kRows * 64u;    // bits one staging slot holds (64 per lane-row)
-constexpr int      kStageWords  = (int)(kFastBits / 32u) + 16;             // carry slot + data + pad (multiple of 4)
-#ifndef HVLC_SLOTS
-#define HVLC_SLOTS 3
+// LDS staging ring: a packed tile waits here, at tile-local bit positions, until its global offset is known.
+// A tile takes exactly the words it needs (carry word + ceil(bits/32) + pad, rounded to 16 bytes), so 3 tiles
+// of 4-bit-per-symbol data are in flight, or kMaxIn of anything that compresses better.
+#ifndef HVLC_RING_WORDS
+#define HVLC_RING_WORDS 5888
 #endif
-constexpr int      kSlots       = HVLC_SLOTS;                       // staging slots (packed tiles in flight) per workgroup
-constexpr uint32_t kPollAge     = 1;                       // a tile's granules are requested once this many newer tiles are packed
+constexpr uint32_t kRingWords   = HVLC_RING_WORDS;         // 23 KiB: six workgroups per CU
+#ifndef HVLC_MAX_INFLIGHT
+#define HVLC_MAX_INFLIGHT 4
+#endif
+constexpr int      kMaxIn       = HVLC_MAX_INFLIGHT;       // packed tiles in flight per workgroup (more only adds drift: measured)
+constexpr uint32_t kGeneralWords = (uint32_t)kDataThreads * 4u * 4u * 31u / 32u + 32u;   // general path: a part of a tile at 31 bits per symbol
+static_assert(kRingWords % 4 == 0 && kRingWords >= kGeneralWords, "the general path uses the ring as one buffer");
+#ifndef HVLC_TICKET_CLASSES
+#define HVLC_TICKET_CLASSES 64
+#endif
+constexpr int      kTicketClasses = HVLC_TICKET_CLASSES;    // ticket counters (workgroup b draws from counter b % kTicketClasses)
+constexpr int      kTicketStride  = 32;                    // uint32 words between counters (one 128-byte line each)
+constexpr int      kTq          = 8;                       // per-workgroup queue of drawn tile numbers (>= kMaxIn + 3)
 constexpr uint64_t kValid       = 1ull << 63;
 constexpr uint64_t kStAgg       = 1ull << 62;              // group granule: aggregate of the group
 constexpr uint64_t kStPre       = 2ull << 62;              // group granule: inclusive prefix through the group
@@ -99,11 +111,13 @@ struct EncodeParams {
     uint64_t*       total_bits;  // user's device word (nullable)
     uint64_t*       result;      // workspace: [0] total bits
     uint32_t*       status;      // workspace: flag word
+    uint32_t*       tickets;     // encoder: kTicketClasses counters, kTicketStride words apart (zeroed per call)
     uint32_t*       bits32;      // encoder: word per tile, kValid32 | bits of the tile (group g = words 64g..64g+63)
     TileRec*        recs;        // encoder: record per tile (+1), see TileRec
     uint64_t*       group_desc;  // granule per group: status | value (encoder and scan)
     uint64_t*       tile_bits;   // scan kernel only: granule per scan tile, kValid | sum
     uint64_t        timeout_ticks;   // s_memrealtime ticks (100 MHz)
+    uint32_t        stall_tile;      // TEST HOOK: this tile's bit count is never published (~0: none); see hvlc_api.hip
     uint32_t        dbg;             // ablation flags, honoured only in -DHVLC_EXPERIMENT builds (tools/)
     uint64_t*       dbg_buf;         // phase stamps [grid][2][16], -DHVLC_EXPERIMENT builds only
     uint64_t*       dbg_tl;          // per-tile timeline [tiles][8] (100 MHz ticks), -DHVLC_EXPERIMENT builds only
@@ -162,35 +176,27 @@ __device__ __forceinline__ void st_word(uint32_t* p, uint32_t v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One polling round of the scout: ONE vector sc1 load instruction fetches the 16-byte records of up to three
-// tiles (lanes 0-11, a dword each) and, for a group leader, 8 group granules (lanes 16-31); the values are
+// One polling round of the scout: ONE vector sc1 load instruction fetches the 16-byte records of up to six
+// tiles (lanes 0-23, a dword each) and, for a group leader, 8 group granules (lanes 32-47); the values are
 // moved to SGPRs (v_readlane) so that everything the scout decides is scalar code.
 // (Polling through the scalar memory path -- s_load ... glc -- was measured too: half the hand-off latency
 // with two pollers (tools/ubench.hip), but with 1535 scouts polling the scalar caches serialise their misses
 // and the kernel ran 15x slower.)
-typedef uint32_t u32x4  __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-
+constexpr int kMaxSlots = 6;       // records the scout can poll per round
 template <bool WINDOW>
-__device__ __forceinline__ void poll_round(const void* const (&a)[3], u32x4 (&r)[3], const void* w, u32x16& x, int lane)
+__device__ __forceinline__ uint32_t poll_round(const void* const (&a)[kMaxSlots], const void* w, int lane)
 {
     const uint32_t* src = (const uint32_t*)a[0];
-    if (lane >= 4)  src = (const uint32_t*)a[1];
-    if (lane >= 8)  src = (const uint32_t*)a[2];
-    if (lane >= 16) src = (const uint32_t*)w - 16 + 4;            // lane 16 -> w[0] (see the index below)
-    const int idx = lane < 16 ? (lane & 3) : lane - 4;             // lanes 16..31: (w - 12)[lane - 4] = w[lane - 16]
+#pragma unroll
+    for (int s = 1; s < kMaxSlots; ++s) if (lane >= 4 * s) src = (const uint32_t*)a[s];
+    if (lane >= 32) src = (const uint32_t*)w;                      // lanes 32..47: the 16 dwords of the window
+    const int idx = lane < 32 ? (lane & 3) : lane - 32;
     uint32_t v = 0;
-    if (lane < 12 || (WINDOW && lane >= 16 && lane < 32))
+    if (lane < 4 * kMaxIn || (WINDOW && lane >= 32 && lane < 48))
         v = __hip_atomic_load(src + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) r[s][k] = (uint32_t)__builtin_amdgcn_readlane((int)v, 4 * s + k);
-    if (WINDOW) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = (uint32_t)__builtin_amdgcn_readlane((int)v, 16 + k);
-    }
+    return v;
 }
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
 {
@@ -366,18 +372,24 @@ struct TileState {
     uint32_t bits;          // T: bits of the tile
     uint32_t pred_tail;     // last 31 bits of the stream before the tile
     uint32_t flags;         // kTsEarlyTail | kTsPrefixReady
+    uint32_t start, need;   // the tile's words in the staging ring: [start, start + need), start = its carry word
     uint32_t seg_rel[kSegsPerTile];   // tile-local bit offset of each segment
 };
 enum : uint32_t { kTsEarlyTail = 1u, kTsPrefixReady = 2u };
 
 struct alignas(16) Smem {
     uint2     lut[256];                     // 2 KiB: {codeword, length}
-    uint32_t  stage[kSlots][kStageWords];   // ring of staging slots; [s][0] is the carry slot
+    uint32_t  ring[kRingWords];             // staging ring (see kRingWords)
     uint32_t  wave_tot[kDataWaves];         // per-wave bit totals of the tile being packed
-    TileState ts[kSlots];
+    TileState ts[kMaxIn];                   // tile n of the workgroup uses ts[n % kMaxIn]
     uint32_t  qtot[kDataWaves];             // general path: per-wave totals of a quarter tile
     uint32_t  n_resolved;                   // scout -> data: tiles whose global offset is known (in order)
-    uint32_t  n_packed_pub;                 // data -> scout: tiles whose bit count / ts[] entry is published
+    uint32_t  n_bits_pub;                   // data -> scout: tiles whose bit count is published (a leader's duty may start)
+    uint32_t  n_packed_pub;                 // data -> scout: tiles whose ts[] entry is complete (their record may be polled)
+    uint32_t  tq[kTq];                      // scout -> data: tile number of the workgroup's n-th tile, at [n % kTq]
+    uint32_t  n_tickets;                    // scout -> data: tiles drawn so far (release)
+    uint32_t  n_final;                      // scout -> data: the workgroup's tile count once the tickets ran out, else ~0
+    uint32_t  n_tix_snap, n_final_snap;     // data waves: per-iteration snapshots (uniform decisions)
     uint32_t  n_res_snap;                   // data waves: per-iteration snapshot of n_resolved (uniform decisions)
     uint32_t  abort_snap;                   // ... and of abort_flag: all four data waves must leave in the same iteration
     uint32_t  bar;                          // arrival counter of the data waves' LDS barrier
@@ -530,7 +542,7 @@ __device__ __forceinline__ void finish_tile(const EncodeParams& p, Smem& sm, uin
     const uint64_t P = ts.prefix;
     const uint32_t T = ts.bits;
     const bool last = (tile == p.num_tiles - 1);
-    const uint32_t* sb = sm.stage[par];
+    const uint32_t* sb = sm.ring + ts.start;
     if (p.offsets && tid < kSegsPerTile && !HVLC_DBG(p, kDbgNoOffsets)) {
         const uint64_t seg = tile * kSegsPerTile + (uint64_t)tid;
         if (seg < p.num_segs) p.offsets[seg] = P + ts.seg_rel[tid];
@@ -554,16 +566,16 @@ __device__ __forceinline__ void finish_tile(const EncodeParams& p, Smem& sm, uin
 
 // General path for one tile (some lane-row holds more than 64 bits; lengths up to 31 allow 496):
 // the tile is re-read (L2) and packed quarter by quarter (4 KiB = wave-contiguous segments 4q..4q+3,
-// at most 3968 words) into both staging buffers taken as one, two symbols (<=62 bits) per
-// put_bits64.  The carry runs through the quarters exactly as it runs through tiles.  Blocking:
-// the caller has no other tile in flight.  Leaves both staging buffers zeroed.
+// at most kGeneralWords words) into the (empty) staging ring taken as one buffer, two symbols (<=62 bits)
+// per put_bits64.  The carry runs through the parts exactly as it runs through tiles.  Blocking:
+// the caller has no other tile in flight.  Leaves the ring zeroed.
 __device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, DataBarrier& bar, uint64_t tile,
                                              uint32_t par, int tid, int lane, int wave)
 {
     const TileState& ts = sm.ts[par];
     const bool last = (tile == p.num_tiles - 1);
     const uint64_t word0 = tile * (uint64_t)kTileWords;
-    uint32_t* const big = &sm.stage[0][0];
+    uint32_t* const big = sm.ring;
     uint64_t Pq    = ts.prefix;
     uint32_t carry = ts.pred_tail;
     const uint32_t T = ts.bits;
@@ -577,7 +589,7 @@ __device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, Da
     }
     for (int qd = 0; qd < kRows; ++qd) {
         bar.sync(sm, lane);                            // previous quarter fully stored
-        zero_words(big, 2u * kStageWords / 4u, tid);
+        zero_words(big, kGeneralWords / 4u, tid);
         const uint64_t wbase = word0 + (uint64_t)qd * (kDataThreads * 4u) + (uint64_t)tid * 4u;
         const uint32_t* in32 = (const uint32_t*)p.in;
         const int n = valid_words(p, wbase);
@@ -613,41 +625,89 @@ __device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, Da
     }
     bar.sync(sm, lane);
     if (tid == 0) st_word(&p.recs[tile + 1].tail, kValid32 | carry);
-    zero_words(big, 2u * kStageWords / 4u, tid);
+    zero_words(big, kGeneralWords / 4u, tid);
 }
 
-// Workgroup-uniform control state of the data waves' ring pipeline.
+// Workgroup-uniform control state of the data waves' pipeline.
+// Tiles are handed out DYNAMICALLY: every tile a workgroup works on is drawn by its scout from one of
+// kTicketClasses atomic counters (draw k of class c is tile 8k + (c + k) % 8, so the eight classes interleave
+// and the group-leader role rotates over them).  A workgroup draws a tile only when it is about to work on it,
+// so (1) no tile ever waits for a workgroup that is not running: forward progress does not depend on the grid
+// being co-resident, and (2) a slow workgroup just draws fewer tiles instead of setting everybody's pace.
+// Tile numbers fit 32 bits (2^32 tiles = 48 TiB of input).
 struct RingCtl {
     uint32_t n_packed = 0, n_stored = 0, n_res = 0;   // tiles packed / stored / resolved (workgroup-local numbering)
-    uint32_t my_tiles;
-    uint32_t b0, G;                                   // tile numbers fit 32 bits (2^32 tiles = 64 TiB of input)
-    __device__ __forceinline__ uint32_t tile(uint32_t n) const { return b0 + n * G; }
+    uint32_t n_loaded = 0;                            // tiles whose input loads have been issued (n_packed or n_packed + 1)
+    uint32_t n_tix = 0, n_final = ~0u;                // snapshots of Smem::n_tickets / n_final
+    uint32_t head = 0;                                // staging ring: where the next tile's words start
+    uint32_t last_need = 0;                           // words the previous tile took (predicts the next one)
 };
 
+// Where `need` words fit in the staging ring: kRingWords = nowhere for now.  Allocations are contiguous (a tile
+// that does not fit before the end of the ring starts over at word 0) and are released in order.
+// `n_stored` = tiles already released (the caller may count one that is being released in this iteration).
+__device__ __forceinline__ uint32_t ring_place(const RingCtl& c, const Smem& sm, uint32_t need, uint32_t n_stored)
+{
+    if (c.n_packed == n_stored) return 0u;                                 // empty (need <= kRingWords is the caller's business)
+    const uint32_t tail = sm.ts[n_stored % kMaxIn].start;                  // oldest tile still in the ring
+    if (c.head > tail) {
+        if (c.head + need <= kRingWords) return c.head;
+        return need <= tail ? 0u : kRingWords;
+    }
+    return (c.head < tail && need <= tail - c.head) ? c.head : kRingWords;  // head == tail with tiles in flight: full
+}
+
+// One blocking step of the data waves while they cannot go on (ring full, or an oversized tile waiting for the
+// ring to drain): store the oldest tile if its offset is known, else sleep; refresh the scout's counters.
+// Returns false if the launch is being aborted.
+__device__ __forceinline__ bool drain_step(const EncodeParams& p, Smem& sm, DataBarrier& bar, RingCtl& c, uint32_t limit,
+                                           int tid, int lane)
+{
+    const bool st_old = c.n_stored < limit && c.n_stored < c.n_res;
+    const uint32_t ss = c.n_stored % kMaxIn;
+    if (st_old) finish_tile(p, sm, sm.tq[c.n_stored % kTq], ss, tid);
+    else        __builtin_amdgcn_s_sleep(8);
+    bar.sync(sm, lane);
+    if (st_old) zero_words(sm.ring + sm.ts[ss].start, sm.ts[ss].need / 4u, tid);
+    if (tid == 0) {
+        sm.n_res_snap = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        sm.abort_snap = __hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    bar.sync(sm, lane);
+    if (sm.abort_snap) return false;
+    c.n_res = sm.n_res_snap;
+    if (st_old) ++c.n_stored;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
-// DATA waves (threads 0..255) of the ring-pipelined encoder.  One loop iteration:
-//   phase X  store the OLDEST packed tile if the scout has resolved its offset (funnel shift from its
-//            slot, coalesced dword stores); look up / concatenate / scan the next tile (registers
-//            only) if a staging slot is free; issue the loads of the tile after it
+// DATA waves of the pipelined encoder.  One loop iteration:
+//   phase X  store the OLDEST packed tile if the scout has resolved its offset (funnel shift out of the
+//            staging ring, coalesced dword stores); look up / concatenate / scan the next tile (registers
+//            only) if the ring is likely to have room for it; issue the loads of the tile after it
 //   -- data barrier --
-//   phase Y  publish the new tile's bit count, pack it into its slot, publish its tail; clear the
-//            slot that was just stored; thread 0 snapshots the scout's progress
+//   phase Y  publish the new tile's bit count, take its words in the ring, pack it, publish its tail;
+//            clear the words of the tile that was just stored; thread 0 snapshots the scout's progress
 //   -- data barrier --
-// A tile that fits no staging slot (more than 4 bits per symbol on average) takes the general path
-// once the ring has drained.
+// A tile that does not fit the ring even when it is empty (more than ~15 bits per symbol on average) takes
+// the general path once the ring has drained.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& sm, RingCtl c, int tid, int lane, int wave)
 {
     uint4 raw[kRows];
-    load_tile(p, c.b0, c.b0 < p.num_full_tiles, wave, lane, raw);
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) raw[r] = make_uint4(0, 0, 0, 0);
     DataBarrier bar;
     STAMP_DECL;
 
-    while (c.n_stored < c.my_tiles) {
-        const bool can_pack = c.n_packed < c.my_tiles && (c.n_packed - c.n_stored) < (uint32_t)kSlots;
+    while (c.n_stored < c.n_final) {
+        const bool have_raw = c.n_loaded > c.n_packed;
         const bool do_store = c.n_stored < c.n_res;
-        const uint32_t sp = c.n_packed % kSlots, ss = c.n_stored % kSlots;
-        const uint32_t cur = c.tile(c.n_packed);
+        const bool can_pack = have_raw && (c.n_packed - c.n_stored) < (uint32_t)kMaxIn &&        // probably fits (if the tile
+                              ring_place(c, sm, c.last_need, c.n_stored + (do_store ? 1u : 0u)) < kRingWords;   // is like the last one,
+                                                                                                 // and with what this iteration frees)
+        const uint32_t sp = c.n_packed % kMaxIn, ss = c.n_stored % kMaxIn;
+        const uint32_t cur = sm.tq[c.n_packed % kTq];                            // meaningful when have_raw
         STAMP_COUNT(8, 1); STAMP_COUNT(9, can_pack ? 1 : 0); STAMP_COUNT(10, do_store ? 1 : 0);
         STAMP_COUNT(11, (!can_pack && !do_store) ? 1 : 0);
 
@@ -655,7 +715,11 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
         uint64_t acc[kRows];
         uint32_t tot[kRows], excl[kRows], rowbase[kRows];
         STAMP(0);
-        if (do_store) { TL(p, c.tile(c.n_stored), 5, tid == 0); finish_tile(p, sm, c.tile(c.n_stored), ss, tid); }
+        if (do_store) {
+            const uint32_t st_tile = sm.tq[c.n_stored % kTq];
+            TL(p, st_tile, 5, tid == 0);
+            finish_tile(p, sm, st_tile, ss, tid);
+        }
         STAMP(1);
         if (can_pack) {
             const bool full = cur < p.num_full_tiles;
@@ -675,29 +739,51 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
             }
             if (lane == 0) sm.wave_tot[wave] = wavetot;
             STAMP(2);
-            if (c.n_packed + 1 < c.my_tiles)              // raw is dead: its registers take the next tile
-                load_tile(p, cur + c.G, cur + c.G < p.num_full_tiles, wave, lane, raw);
-        } else if (!do_store) {
-            __builtin_amdgcn_s_sleep(8);                  // ring full and the oldest tile unresolved: wait for the scout
+        }
+        if ((can_pack || !have_raw) && c.n_loaded < c.n_tix) {   // raw is dead or empty: its registers take the next drawn tile
+            const uint32_t nxt = sm.tq[c.n_loaded % kTq];
+            load_tile(p, nxt, nxt < p.num_full_tiles, wave, lane, raw);
+            ++c.n_loaded;
+        } else if (!can_pack && !do_store) {
+            __builtin_amdgcn_s_sleep(8);                  // nothing to do this round: wait for the scout
         }
         STAMP(3);
         bar.sync(sm, lane);                                                   // data barrier 1
         STAMP(4);
 
         // ---------------- phase Y ----------------
+        bool release = do_store;                           // every wave is past its part of the store: clear its words; they
+        if (release) zero_words(sm.ring + sm.ts[ss].start, sm.ts[ss].need / 4u, tid);   // count as free after the next barrier
         bool slow = false;
         if (can_pack) {
             uint32_t T = 0, wavebase = 0, clast = 0;
 #pragma unroll
             for (int w2 = 0; w2 < kDataWaves; ++w2) { clast = sm.wave_tot[w2]; if (w2 < wave) wavebase += clast; T += clast; }
-            slow = T > kFastBits;                         // fits no staging slot: general path, once the ring is empty
+            if (tid == 0) {
+                if (cur != p.stall_tile) st_word(&p.bits32[cur], kValid32 | T);   // publish before anything else
+                TL(p, cur, 0, true);
+                // a group leader's scout starts on this alone, even if the tile has to wait for room in the ring
+                __hip_atomic_store(&sm.n_bits_pub, c.n_packed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            const uint32_t need = (((T + 31u) >> 5) + 2u + 3u) & ~3u;  // carry word + data + the word store_words reads ahead
+            slow = need > kRingWords;                        // fits no ring: general path, once the ring is empty
+            uint32_t start = 0;
+            if (!slow) {
+                // rare: the tile is bigger than predicted and the ring has no room yet -- store older tiles until it has
+                while ((start = ring_place(c, sm, need, c.n_stored)) >= kRingWords) {
+                    if (release) { bar.sync(sm, lane); ++c.n_stored; release = false; continue; }
+                    if (!drain_step(p, sm, bar, c, c.n_packed, tid, lane)) return;
+                }
+                c.head = start + need;
+                c.last_need = need;
+            }
             const bool early_tail = !slow && clast >= 31u;   // the tile's last 31 bits are all written by the last data wave
             if (tid == 0) {
-                st_word(&p.bits32[cur], kValid32 | T);               // publish before anything else
-                TL(p, cur, 0, true);
                 sm.ts[sp].bits  = T;
                 sm.ts[sp].flags = early_tail ? kTsEarlyTail : 0u;
-                // the scout needs only the bit count to start this tile's look-back (it never reads the slot)
+                sm.ts[sp].start = start;
+                sm.ts[sp].need  = slow ? 0u : need;
+                // the scout needs only this to poll the tile's record (it never reads the packed words)
                 __hip_atomic_store(&sm.n_packed_pub, c.n_packed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (lane == 0) {
@@ -705,7 +791,7 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
                 for (int r = 0; r < kRows; ++r) sm.ts[sp].seg_rel[wave * kRows + r] = wavebase + rowbase[r];
             }
             if (!slow) {
-                uint32_t* const st = sm.stage[sp] + 1;
+                uint32_t* const st = sm.ring + start + 1;
 #pragma unroll
                 for (int r = 0; r < kRows; ++r) {
                     const uint32_t q = wavebase + rowbase[r] + excl[r];
@@ -725,43 +811,32 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
                 if (early_tail && wave == kDataWaves - 1 && lane == 0)   // same-wave LDS ops complete in order
                     st_word(&p.recs[(uint64_t)cur + 1].tail, kValid32 | extract_tail(st, T));
             }
+            ++c.n_packed;
         }
         STAMP(5);
-        if (do_store) zero_words(sm.stage[ss], (sm.ts[ss].bits >> 7) + 2u, tid);
         if (tid == 0) {
-            sm.n_res_snap = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            sm.abort_snap = __hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            sm.n_res_snap   = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            sm.abort_snap   = __hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            sm.n_final_snap = __hip_atomic_load(&sm.n_final, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            sm.n_tix_snap   = __hip_atomic_load(&sm.n_tickets, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         STAMP(6);
         bar.sync(sm, lane);                                                   // data barrier 2
         STAMP(7);
         if (sm.abort_snap) return;                        // uniform: one thread sampled the flag before the barrier
-        c.n_res = sm.n_res_snap;
-        if (do_store) ++c.n_stored;
-        if (can_pack) ++c.n_packed;
+        c.n_res = sm.n_res_snap; c.n_tix = sm.n_tix_snap; c.n_final = sm.n_final_snap;
+        if (release) ++c.n_stored;
+        if (c.n_packed == c.n_stored) c.head = 0;         // empty ring: start over at word 0
 
         if (slow) {
             // Oversized tile: drain the ring (store every older tile), wait for its own offset, then encode
-            // it on the general path.  Its slot index is free by construction (the ring is empty).
+            // it on the general path, which uses the whole (empty) ring and leaves it zeroed.
             const uint32_t me = c.n_packed - 1;
-            for (;;) {
-                const bool st_old = c.n_stored < me && c.n_stored < c.n_res;
-                if (st_old) finish_tile(p, sm, c.tile(c.n_stored), c.n_stored % kSlots, tid);
-                else        __builtin_amdgcn_s_sleep(8);
-                bar.sync(sm, lane);
-                if (st_old) zero_words(sm.stage[c.n_stored % kSlots], (sm.ts[c.n_stored % kSlots].bits >> 7) + 2u, tid);
-                if (tid == 0) {
-                    sm.n_res_snap = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    sm.abort_snap = __hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                bar.sync(sm, lane);
-                if (sm.abort_snap) return;
-                c.n_res = sm.n_res_snap;
-                if (st_old) ++c.n_stored;
-                if (c.n_stored == me && c.n_res > me) break;
-            }
+            while (!(c.n_stored == me && c.n_res > me))
+                if (!drain_step(p, sm, bar, c, me, tid, lane)) return;
             general_tile(p, sm, bar, cur, sp, tid, lane, wave);
             ++c.n_stored;
+            c.head = 0;
             bar.sync(sm, lane);
         }
     }
@@ -782,7 +857,7 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
 // the chain packed -> leader -> records is three hand-offs whatever the input size.
 // The scout free-runs: it takes no part in the data waves' barrier and hands results over through LDS.
 // ------------------------------------------------------------------------------------------------
-static_assert(kSlots <= 3, "the scout polls at most three records per round");
+static_assert(kMaxIn <= kMaxSlots, "the scout polls at most kMaxSlots records per round");
 struct LeaderDuty {
     bool     active = false, have_bits = false, win_done = false;
     uint32_t g = 0, n = 0;      // group, tiles in it
@@ -794,39 +869,63 @@ struct LeaderDuty {
 
 __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& sm, RingCtl c, int lane)
 {
-    bool     act[kSlots], done[kSlots];
-    uint32_t num[kSlots];               // workgroup-local number of the tile a slot holds
+    bool     act[kMaxIn], done[kMaxIn];
+    uint32_t til[kMaxIn];               // tile a slot holds (tile n of the workgroup uses slot n % kMaxIn)
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) { act[s] = false; done[s] = false; num[s] = 0; }
+    for (int s = 0; s < kMaxIn; ++s) { act[s] = false; done[s] = false; til[s] = 0; }
     uint32_t n_started = 0, n_done = 0; // tiles whose record is being polled / handed to the data waves
     uint32_t n_duty = 0;                // tiles already checked for the group-leader role
     LeaderDuty d;
     uint32_t rounds = 0;
     uint64_t t_progress = 0;
-    const uint32_t last_tile = (uint32_t)p.num_tiles - 1u;
+    const uint32_t ntiles = (uint32_t)p.num_tiles, last_tile = ntiles - 1u;
+    // tickets: draw k of class cls is tile C*k + (cls + k) % C
+    const uint32_t cls = blockIdx.x % (uint32_t)kTicketClasses;
+    uint32_t n_tix = 0, n_final = ~0u;  // tiles drawn; the total once the tickets ran out
+    bool     tix_inflight = false;
+    uint32_t tix_k = 0;                 // lane 0: the value a ticket draw returned (valid one round later)
 
-    while (n_done < c.my_tiles) {
+    while (n_done < n_final) {
         bool progress = false;
+
+        // (0) the ticket drawn in the previous round has arrived
+        if (tix_inflight) {
+            const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)tix_k);
+            tix_inflight = false;
+            progress = true;
+            if ((uint64_t)k * kTicketClasses >= (uint64_t)ntiles) {
+                n_final = n_tix;
+                if (lane == 0) __hip_atomic_store(&sm.n_final, n_final, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                const uint32_t t = k * (uint32_t)kTicketClasses + ((cls + k) % (uint32_t)kTicketClasses);
+                if (t < ntiles) {       // (a draw in the last, partial block may fall behind the end: draw again)
+                    if (lane == 0) {
+                        sm.tq[n_tix % kTq] = t;
+                        __hip_atomic_store(&sm.n_tickets, n_tix + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    ++n_tix;
+                }
+            }
+        }
 
         // (1) this round's requests: the leader's bit counts (vector, asynchronous), then the records of the
         //     tiles in flight and, for a leader, 8 group granules, in one scalar block
         uint32_t bv = kValid32;
         if (d.active && !d.have_bits && (uint32_t)lane < d.n)
             bv = __hip_atomic_load(&p.bits32[(uint64_t)d.g * kGroupTiles + (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const void* a[3];
-        u32x4 r[3];
+        const void* a[kMaxSlots];
+        uint32_t pv;                     // lanes 0-23: the records of the tiles in flight; lanes 32-47: the leader's window
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-            a[s] = &p.recs[(s < kSlots && act[s < kSlots ? s : 0]) ? (uint64_t)c.tile(num[s < kSlots ? s : 0]) : 0ull];
+        for (int s = 0; s < kMaxSlots; ++s)
+            a[s] = &p.recs[(s < kMaxIn && act[s < kMaxIn ? s : 0]) ? (uint64_t)til[s < kMaxIn ? s : 0] : 0ull];
         if (d.active && !d.win_done) {
             const int32_t c0 = d.j & ~7;
-            u32x16 w;
-            poll_round<true>(a, r, p.group_desc + c0, w, lane);
+            pv = poll_round<true>(a, p.group_desc + c0, lane);
             bool stop = false;
 #pragma unroll
             for (int i = 7; i >= 0; --i) {
                 if (!stop && c0 + i <= d.j) {
-                    const uint64_t v  = ((uint64_t)w[2 * i + 1] << 32) | (uint64_t)w[2 * i];
+                    const uint64_t v  = ((uint64_t)lane_value(pv, 33 + 2 * i) << 32) | (uint64_t)lane_value(pv, 32 + 2 * i);
                     const uint32_t st = (uint32_t)(v >> 62);
                     if (st == 0u) stop = true;                            // not published yet: again next round
                     else {
@@ -839,23 +938,33 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             }
             if (!d.win_done && d.j < 0) d.win_done = true;                // walked down to the start of the stream
         } else {
-            u32x16 unused;
-            poll_round<false>(a, r, nullptr, unused, lane);
+            pv = poll_round<false>(a, nullptr, lane);
+        }
+
+        // draw the next tile once the data waves are within two tiles of the last one drawn; the atomic is issued
+        // BEHIND this round's polls (in-order return) and its value is used at the top of the next round
+        if (n_final == ~0u && !tix_inflight &&
+            n_tix - __hip_atomic_load(&sm.n_packed_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2u) {
+            if (lane == 0)
+                tix_k = __hip_atomic_fetch_add(&p.tickets[cls * (uint32_t)kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tix_inflight = true;
         }
 
         // (2) the tiles in flight: resolved when the leader's offset and the predecessor's tail are both there
+        const uint64_t vm = __ballot((pv >> 31) != 0u);                 // valid bits of all polled dwords at once
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) {
-            if (act[s] && !done[s]) {
-                uint64_t P  = ((uint64_t)r[s].y << 32) | (uint64_t)r[s].x;
-                uint32_t tl = r[s].z;
-                if (HVLC_DBG(p, kDbgNoLookback)) { P = kValid | ((uint64_t)c.tile(num[s]) * 36400ull); tl = kValid32; }
-                if ((P >> 63) != 0ull && (tl >> 31) != 0u) {
+        for (int s = 0; s < kMaxIn; ++s) {
+            if (act[s] && !done[s] && (((vm >> (4 * s + 1)) & 3ull) == 3ull || HVLC_DBG(p, kDbgNoLookback))) {
+                uint64_t P  = ((uint64_t)lane_value(pv, 4 * s + 1) << 32) | (uint64_t)lane_value(pv, 4 * s);
+                uint32_t tl = lane_value(pv, 4 * s + 2);
+                if (HVLC_DBG(p, kDbgNoLookback)) { P = kValid | ((uint64_t)til[s] * 36400ull); tl = kValid32; }
+                {
                     if (lane == 0) {
                         sm.ts[s].prefix    = P & kValMask;
                         sm.ts[s].pred_tail = tl & 0x7fffffffu;
-                        sm.stage[s][0]     = tl & 0x7fffffffu;
+                        sm.ring[sm.ts[s].start] = tl & 0x7fffffffu;             // the carry word of the packed tile
                     }
+                    TL(p, til[s], 4, lane == 0);
                     done[s] = true;
                     progress = true;
                 }
@@ -864,14 +973,14 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
         // hand the resolved tiles over in order
         uint32_t nd = n_done;
 #pragma unroll
-        for (int k = 0; k < kSlots; ++k) {
-            const uint32_t sl = nd % kSlots;
+        for (int k = 0; k < kMaxIn; ++k) {
+            const uint32_t sl = nd % kMaxIn;
             bool dn = false;
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) if ((uint32_t)s == sl) dn = done[s] && act[s];
+            for (int s = 0; s < kMaxIn; ++s) if ((uint32_t)s == sl) dn = done[s] && act[s];
             if (nd < n_started && dn) {
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) if ((uint32_t)s == sl) { done[s] = false; act[s] = false; }
+                for (int s = 0; s < kMaxIn; ++s) if ((uint32_t)s == sl) { done[s] = false; act[s] = false; }
                 ++nd;
             }
         }
@@ -889,6 +998,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
                 d.A         = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 d.have_bits = true;
                 progress    = true;
+                TL(p, (uint64_t)d.g * kGroupTiles + d.n - 1u, 2, lane == 0);
                 if (lane == 0 && !d.win_done) st_granule(&p.group_desc[d.g], kStAgg | (uint64_t)d.A);
             }
         }
@@ -896,22 +1006,26 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             if (lane == 0) st_granule(&p.group_desc[d.g], kStPre | (d.E + (uint64_t)d.A));   // later leaders wait for this
             if ((uint32_t)lane < d.n)
                 st_granule(&p.recs[(uint64_t)d.g * kGroupTiles + (uint32_t)lane].P, kValid | (d.E + (uint64_t)d.excl_in));
+            TL(p, (uint64_t)d.g * kGroupTiles + d.n - 1u, 3, lane == 0);
             d.active = false;
             progress = true;
         }
 
         // (4) newly packed tiles: start polling their records; the last tile of a group starts that group's duty
         const uint32_t np = __hip_atomic_load(&sm.n_packed_pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (n_started < np && n_started - n_done < (uint32_t)kSlots) {
-            const uint32_t sl = n_started % kSlots;
+        while (n_started < np && n_started - n_done < (uint32_t)kMaxIn) {
+            const uint32_t sl = n_started % kMaxIn;
+            const uint32_t t  = (uint32_t)__builtin_amdgcn_readfirstlane((int)sm.tq[n_started % kTq]);
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s)
-                if ((uint32_t)s == sl) { act[s] = true; done[s] = false; num[s] = n_started; }
+            for (int s = 0; s < kMaxIn; ++s)
+                if ((uint32_t)s == sl) { act[s] = true; done[s] = false; til[s] = t; }
+            TL(p, t, 1, lane == 0);
             ++n_started;
             progress = true;
         }
-        while (!d.active && n_duty < n_started && !HVLC_DBG(p, kDbgNoLookback)) {
-            const uint32_t t = c.tile(n_duty);
+        const uint32_t nb = __hip_atomic_load(&sm.n_bits_pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (!d.active && n_duty < nb && !HVLC_DBG(p, kDbgNoLookback)) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)sm.tq[n_duty % kTq]);
             ++n_duty;
             if ((t & (uint32_t)(kGroupTiles - 1)) == (uint32_t)(kGroupTiles - 1) || t == last_tile) {
                 d.active = true; d.have_bits = false;
@@ -925,7 +1039,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
         // watchdog: nothing moved for timeout_ticks -> give up (and make every other workgroup give up)
         if (progress) { rounds = 0; t_progress = 0; }
         else {
-            if (n_started == n_done && !d.active) __builtin_amdgcn_s_sleep(4);   // nothing in flight: wait for the data waves
+            if (n_started == n_done && !d.active && !tix_inflight) __builtin_amdgcn_s_sleep(4);   // nothing in flight: wait for the data waves
             if ((++rounds & 255u) == 0u) {
                 const uint64_t now = __builtin_amdgcn_s_memrealtime();
                 const uint32_t st  = atomicOr(p.status, 0u);  // RMW: coherent with the other workgroups' atomicOr
@@ -940,17 +1054,16 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
     }
 }
 
-// The persistent, ring-pipelined encoder.  A workgroup = 4 DATA waves + 1 SCOUT wave.  It owns tiles
-// b, b+G, b+2G, ... (G = grid size) and keeps up to kSlots of them packed in LDS while the scout
-// resolves their global bit offsets, so HBM latency, the inter-XCD granule round trips and the LDS
-// bit packing of up to kSlots+1 tiles overlap inside one workgroup, on top of the overlap between the
-// workgroups of a CU.
+// The persistent, pipelined encoder.  A workgroup = 3 DATA waves + 1 SCOUT wave (one wave per SIMD).  It draws
+// tiles from the ticket counters and keeps up to kMaxIn of them packed in its LDS ring while the scout waits
+// for their global bit offsets, so HBM latency, the inter-workgroup hand-offs and the LDS bit packing of
+// several tiles overlap inside one workgroup, on top of the overlap between the workgroups of a CU.
 #ifndef HVLC_WAVES_PER_EU
 #define HVLC_WAVES_PER_EU 6
 #endif
 // LDS is passed as dynamic shared memory (sizeof(Smem)) so that the register allocator honours the
 // waves-per-SIMD request below instead of the occupancy the static LDS size would imply: 80 VGPRs
-// leave 24 wave slots per CU for the 20 waves of four 5-wave workgroups (slack for co-residency).
+// = 6 waves per SIMD = six 4-wave workgroups per CU.
 __global__ void __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(HVLC_WAVES_PER_EU, 8)))
 k_encode(EncodeParams p)
 {
@@ -967,15 +1080,15 @@ k_encode(EncodeParams p)
         return;
     }
     if (tid < 256) sm.lut[lut_slot((uint32_t)tid)] = p.lut[tid];
-    if (tid < kDataThreads) zero_words(&sm.stage[0][0], (uint32_t)kSlots * kStageWords / 4u, tid);
-    if (tid == 0) { sm.abort_flag = 0u; sm.abort_snap = 0u; sm.n_resolved = 0u; sm.n_packed_pub = 0u; sm.n_res_snap = 0u; sm.bar = 0u; }
-    if (tid < kSlots) { sm.ts[tid].bits = 0u; sm.ts[tid].flags = 0u; }
+    if (tid < kDataThreads) zero_words(sm.ring, kRingWords / 4u, tid);
+    if (tid == 0) {
+        sm.abort_flag = 0u; sm.abort_snap = 0u; sm.n_resolved = 0u; sm.n_packed_pub = 0u; sm.n_res_snap = 0u; sm.bar = 0u;
+        sm.n_tickets = 0u; sm.n_final = ~0u; sm.n_tix_snap = 0u; sm.n_final_snap = ~0u; sm.n_bits_pub = 0u;
+    }
+    if (tid < kMaxIn) { sm.ts[tid].bits = 0u; sm.ts[tid].flags = 0u; sm.ts[tid].start = 0u; sm.ts[tid].need = 0u; }
 
     RingCtl c;
-    c.G = gridDim.x; c.b0 = blockIdx.x;
-    const uint32_t ntiles = (uint32_t)p.num_tiles;
-    if (c.b0 >= ntiles) return;
-    c.my_tiles = (ntiles - c.b0 + c.G - 1) / c.G;
+    if (blockIdx.x >= (uint32_t)p.num_tiles) return;
     __syncthreads();                                  // the only workgroup-wide barrier: LDS initialised
     if (wave == kDataWaves) encode_scout_wave(p, sm, c, lane);
     else           encode_data_waves(p, sm, c, tid, lane, wave);

@@ -295,15 +295,14 @@ def test_stitch_two_shards_one_gpu(enc, golden):
 
 
 def test_timeout_is_reported_not_a_hang(golden, monkeypatch):
-    """A grid that cannot be co-resident (forced 4x over-subscription) must end in HVLC_ERR_TIMEOUT within
-    the configured bound, not in a hung GPU; a normal encode on a fresh context works afterwards."""
+    """If a tile's bit count never arrives (test hook: tile 1000 does not publish it) every later tile would
+    wait for ever: the bounded waits must end in HVLC_ERR_TIMEOUT within the configured bound, not in a hung
+    GPU, and a normal encode on a fresh context works afterwards."""
     import time
     monkeypatch.setenv("HVLC_TIMEOUT_MS", "200")
+    monkeypatch.setenv("HVLC_TEST_STALL_TILE", "1000")
     e2 = hvlc.Encoder(0, 1 << 24)
-    info = e2.launch_info()
-    forced = 2 * info["compute_units"] * info["blocks_per_cu"]   # twice what can be resident, two+ tiles each:
-    monkeypatch.setenv("HVLC_TEST_FORCE_GRID", str(forced))      # resident workgroups wait for queued ones forever
-    x = np.tile(golden["period"], 256).view(np.uint32)          # 64 MiB = 4096 tiles
+    x = np.tile(golden["period"], 256).view(np.uint32)          # 64 MiB = 5462 tiles
     d_in = _dev(x); d_tab = e2.table_to_device(golden["cw"], golden["cl"])
     out = torch.empty(hvlc.out_capacity_words(x.size, 21), dtype=torch.int32, device="cuda")
     t0 = time.time()
@@ -312,13 +311,28 @@ def test_timeout_is_reported_not_a_hang(golden, monkeypatch):
     dt = time.time() - t0
     assert rc == hvlc.ERR_TIMEOUT, rc
     assert dt < 5.0, dt
-    monkeypatch.delenv("HVLC_TEST_FORCE_GRID")
+    monkeypatch.delenv("HVLC_TEST_STALL_TILE")
     e2.close()
     e3 = hvlc.Encoder(0, 1 << 24)
     o3, _, bits = e3.encode(d_in, d_tab, max_len=21)
     ref, rbits = O.encode(x, golden["cw"], golden["cl"])
     assert bits == rbits and torch.equal(o3[: bits // 32 + 1].cpu(), torch.from_numpy(ref.view(np.int32)))
     e3.close()
+
+
+@pytest.mark.parametrize("factor", [2, 4])
+def test_oversubscribed_grid_still_encodes(golden, monkeypatch, factor):
+    """Tiles are drawn by running workgroups only, so a grid that is NOT co-resident (forced to 2x / 4x what
+    the device holds) must still produce the exact stream: forward progress does not depend on residency."""
+    e2 = hvlc.Encoder(0, 1 << 24)
+    info = e2.launch_info()
+    monkeypatch.setenv("HVLC_TEST_FORCE_GRID", str(factor * info["compute_units"] * info["blocks_per_cu"]))
+    x = np.tile(golden["period"], 512).view(np.uint32)          # 128 MiB = 10923 tiles
+    d_tab = e2.table_to_device(golden["cw"], golden["cl"])
+    o, offs, bits = e2.encode(_dev(x), d_tab, max_len=21)
+    ref, rbits = O.encode(x, golden["cw"], golden["cl"])
+    assert bits == rbits and torch.equal(o[: bits // 32 + 1].cpu(), torch.from_numpy(ref.view(np.int32)))
+    e2.close()
 
 
 def test_generator_and_histogram_match_oracle(enc, golden):

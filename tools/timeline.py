@@ -23,7 +23,7 @@ def main():
     cw, cl = hvlc.huffman_table(hist); d_tab = enc.table_to_device(cw, cl)
     out = torch.empty(hvlc.out_capacity_words(n // 4, int(cl.max())), dtype=torch.int32, device="cuda")
     offs = torch.empty(hvlc.num_segments(n // 4), dtype=torch.int64, device="cuda")
-    ntiles = n // 16384
+    ntiles = n // 12288 + (1 if n % 12288 else 0)
     for it in range(3):
         tl = torch.zeros(ntiles * 8, dtype=torch.int64, device="cuda")
         L.hvlc_debug_set_timeline(C.c_void_p(tl.data_ptr()))
@@ -33,30 +33,38 @@ def main():
     G = enc.launch_info()["grid_blocks"]
     t0 = t[:, 0].min()
     us = lambda x: (x - t0) / 100.0
-    pack, start, ga_nl, ga_l, res, store, rounds = us(t[:, 0]), us(t[:, 1]), us(t[:, 2]), us(t[:, 3]), us(t[:, 4]), us(t[:, 5]), t[:, 6]
+    # 0 bits published (packed), 1 scout starts polling the record, 2 (leader tile) group bits complete,
+    # 3 (leader tile) group prefix + records published, 4 record seen valid, 5 store begins
+    pack, start, lbits, lpub, res, store = us(t[:, 0]), us(t[:, 1]), us(t[:, 2]), us(t[:, 3]), us(t[:, 4]), us(t[:, 5])
     print(f"grid {G} tiles {ntiles} rc {rc} span {us(t[:,5].max()):.1f} us")
     def st(name, x):
-        print(f"  {name:34s} mean {x.mean():7.2f}  p50 {np.percentile(x,50):7.2f}  p90 {np.percentile(x,90):7.2f}  max {x.max():7.2f}")
+        print(f"  {name:44s} mean {x.mean():7.2f}  p50 {np.percentile(x,50):7.2f}  p90 {np.percentile(x,90):7.2f}  max {x.max():7.2f}")
     mid = slice(ntiles // 4, 3 * ntiles // 4)
-    st("pack -> scout starts (us)", (start - pack)[mid])
-    st("start -> in-group bits complete", (np.where(t[:, 3] > 0, ga_l, ga_nl) - start)[mid])
-    st("in-group complete -> resolved", (res - np.where(t[:, 3] > 0, ga_l, ga_nl))[mid])
+    st("pack -> scout starts polling (us)", (start - pack)[mid])
     st("pack -> resolved", (res - pack)[mid])
     st("resolved -> store begins", (store - res)[mid])
     st("pack -> store", (store - pack)[mid])
-    st("scout steps per tile", rounds[mid])
-    lead = np.arange(ntiles) % 64 == 63
-    st("LEADER pack -> GA published", (ga_l - pack)[lead][ntiles // 256: 3 * ntiles // 256])
-    st("LEADER pack -> resolved(GP)", (res - pack)[lead][ntiles // 256: 3 * ntiles // 256])
-    # spread of pack times inside a group, and GA publication relative to the group's last pack
-    pk = pack[: ntiles // 64 * 64].reshape(-1, 64)
-    st("group: last pack - first pack", (pk.max(axis=1) - pk.min(axis=1))[ntiles // 256: 3 * ntiles // 256])
-    gal = ga_l[lead]
-    st("group: GA published - last pack", (gal - pk.max(axis=1))[ntiles // 256: 3 * ntiles // 256])
-    gp = res[lead]
-    st("group: GP published - last pack", (gp - pk.max(axis=1))[ntiles // 256: 3 * ntiles // 256])
-    # generation structure: pack time of local tile n of each WG
+    ng = ntiles // 64
+    gsl = slice(ng // 4, 3 * ng // 4)
+    pk = pack[: ng * 64].reshape(ng, 64)
+    lead = np.arange(ng) * 64 + 63
+    st("group: last pack - first pack", (pk.max(axis=1) - pk.min(axis=1))[gsl])
+    st("group: leader pack - last pack of group", (pack[lead] - pk.max(axis=1))[gsl])
+    st("group: bits complete - last pack", (lbits[lead] - pk.max(axis=1))[gsl])
+    st("group: records published - bits complete", (lpub[lead] - lbits[lead])[gsl])
+    st("group: records published - last pack", (lpub[lead] - pk.max(axis=1))[gsl])
+    rs = res[: ng * 64].reshape(ng, 64)
+    st("tile: record seen - records published", (rs - lpub[lead][:, None])[gsl].ravel())
+    st("group: publish time - previous group's", np.diff(lpub[lead])[gsl])
     gen = pack[: ntiles // G * G].reshape(-1, G)
     print("  generation pack time (mean over WGs) first 12:", np.round(gen.mean(axis=1)[:12], 1))
     print("  generation pack spread (max-min)   first 12:", np.round((gen.max(axis=1) - gen.min(axis=1))[:12], 1))
+    print("  generation pack spread (p95-p5)    first 12:", np.round((np.percentile(gen, 95, axis=1) - np.percentile(gen, 5, axis=1))[:12], 1))
+    # how far out of tile order are tiles packed?  lateness = pack time minus the running max of earlier tiles' pack times
+    runmax = np.maximum.accumulate(pack)
+    st("tile: (latest earlier pack) - own pack", (np.concatenate([[0], runmax[:-1]]) - pack)[mid])
+    # per-class progress (tile % 8 classes interleave): pack time of every 8th tile
+    for cidx in range(0, 8, 7):
+        x = pack[cidx::8]
+        print(f"  class-slot {cidx}: pack time at tile 25/50/75 %:", np.round([x[len(x)//4], x[len(x)//2], x[3*len(x)//4]], 1))
 main()
