@@ -49,28 +49,28 @@ namespace hvlc {
 
 constexpr int      kThreads     = 256;                     // block size of the small kernels
 #ifndef HVLC_DATA_WAVES
-#define HVLC_DATA_WAVES 3
+#define HVLC_DATA_WAVES 7
 #endif
 constexpr int      kDataWaves   = HVLC_DATA_WAVES;         // data waves per encoder workgroup (+1 scout wave)
 constexpr int      kDataThreads = 64 * kDataWaves;
-constexpr int      kEncThreads  = kDataThreads + 64;       // k_encode: with 3+1 waves a workgroup is one wave per SIMD
+constexpr int      kEncThreads  = kDataThreads + 64;       // k_encode: 7+1 waves = two waves per SIMD whatever the placement
 #ifndef HVLC_ROWS
 #define HVLC_ROWS 4
 #endif
 constexpr int      kRows        = HVLC_ROWS;               // 16-byte rows per lane per tile
-constexpr int      kTileWords   = kDataThreads * kRows * 4;   // 3072 words = 12 KiB
+constexpr int      kTileWords   = kDataThreads * kRows * 4;   // 7168 words = 28 KiB
 constexpr int      kTileVec     = kDataThreads * kRows;    // uint4s per tile
 constexpr int      kSegWords    = 256;
-constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 12: wave w owns segments 4w..4w+3
+constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 28: wave w owns segments 4w..4w+3
 constexpr int      kGroupTiles  = 64;
 constexpr int      kScanTile    = 4096;                    // elements per workgroup pass of k_exclusive_scan
 // LDS staging ring: a packed tile waits here, at tile-local bit positions, until its global offset is known.
 // A tile takes exactly the words it needs (carry word + ceil(bits/32) + pad, rounded to 16 bytes), so 3 tiles
-// of 4-bit-per-symbol data are in flight, or kMaxIn of anything that compresses better.
+// of 4-bit-per-symbol data (14 KiB each) are in flight, or kMaxIn of anything that compresses better.
 #ifndef HVLC_RING_WORDS
-#define HVLC_RING_WORDS 5888
+#define HVLC_RING_WORDS 12288
 #endif
-constexpr uint32_t kRingWords   = HVLC_RING_WORDS;         // 23 KiB: six workgroups per CU
+constexpr uint32_t kRingWords   = HVLC_RING_WORDS;         // 48 KiB: three 8-wave workgroups per CU
 #ifndef HVLC_MAX_INFLIGHT
 #define HVLC_MAX_INFLIGHT 4
 #endif
