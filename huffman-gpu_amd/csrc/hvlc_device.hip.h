@@ -171,6 +171,14 @@ __device__ __forceinline__ void st_granule(uint64_t* p, uint64_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// A value every lane of the wave read from the same LDS / kernarg word: tell the compiler it is wave-uniform
+// (it then lives in an SGPR and feeds scalar address arithmetic instead of per-lane 64-bit VGPR math).
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t uni64(uint64_t x)
+{
+    return ((uint64_t)uni((uint32_t)(x >> 32)) << 32) | (uint64_t)uni((uint32_t)x);
+}
+
 __device__ __forceinline__ void st_word(uint32_t* p, uint32_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -183,17 +191,15 @@ __device__ __forceinline__ void st_word(uint32_t* p, uint32_t v)
 // with two pollers (tools/ubench.hip), but with 1535 scouts polling the scalar caches serialise their misses
 // and the kernel ran 15x slower.)
 constexpr int kMaxSlots = 6;       // records the scout can poll per round
+// rec_off: per lane, the byte offset (from p.recs) of the dword this lane polls: lane 4s+k -> dword k of slot s's record
 template <bool WINDOW>
-__device__ __forceinline__ uint32_t poll_round(const void* const (&a)[kMaxSlots], const void* w, int lane)
+__device__ __forceinline__ uint32_t poll_round(const EncodeParams& p, uint32_t rec_off, const void* w, int lane)
 {
-    const uint32_t* src = (const uint32_t*)a[0];
-#pragma unroll
-    for (int s = 1; s < kMaxSlots; ++s) if (lane >= 4 * s) src = (const uint32_t*)a[s];
-    if (lane >= 32) src = (const uint32_t*)w;                      // lanes 32..47: the 16 dwords of the window
-    const int idx = lane < 32 ? (lane & 3) : lane - 32;
+    const char* src = (const char*)p.recs + rec_off;
+    if (WINDOW && lane >= 32) src = (const char*)w + (uint32_t)(lane - 32) * 4u;   // lanes 32..47: the 16 dwords of the window
     uint32_t v = 0;
     if (lane < 4 * kMaxIn || (WINDOW && lane >= 32 && lane < 48))
-        v = __hip_atomic_load(src + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __hip_atomic_load((const uint32_t*)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return v;
 }
 __device__ __forceinline__ uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -347,6 +353,19 @@ __device__ __forceinline__ void encode16(const uint4& v, int nvalid, const uint2
 }
 #undef HVLC_SYM
 
+// The hot-path form: n <= 64 bits, n == 0 allowed, always three ORs (the third is usually zero) -- no
+// per-lane branches.  Needs two readable words behind the tile's last data word (the ring allocation has them).
+__device__ __forceinline__ void put_bits64_flat(uint32_t* st, uint32_t q, uint64_t acc, uint32_t n)
+{
+    const uint64_t val = acc << ((64u - n) & 63u);                 // left-align the n bits (n == 0: acc == 0)
+    const uint32_t hi = (uint32_t)(val >> 32), lo = (uint32_t)val;
+    const uint32_t sh = q & 31u;
+    uint32_t* w = st + (q >> 5);
+    lds_or(w,     hi >> sh);
+    lds_or(w + 1, __builtin_amdgcn_alignbit(hi, lo, sh));          // sh == 0: lo
+    lds_or(w + 2, __builtin_amdgcn_alignbit(lo, 0u, sh));          // sh == 0: 0
+}
+
 // A lane-row whose 16 codewords exceed 64 bits (lengths up to 31 allow 496): two symbols (<=62 bits)
 // per put_bits64.  Rare with real tables, so it runs as a divergent branch of the fast path.
 __device__ __forceinline__ void put_row_pairs(uint32_t* st, uint32_t q, const uint32_t (&wraw)[4], int nvalid,
@@ -363,6 +382,20 @@ __device__ __forceinline__ void put_row_pairs(uint32_t* st, uint32_t q, const ui
             put_bits64(st, q, ((uint64_t)e0.x << e1.y) | e1.x, e0.y + e1.y);
             q += e0.y + e1.y;
         }
+    }
+}
+
+// The same for a lane-row of a FULL tile read back from memory, as a rolled loop (cold code: keep it small).
+__device__ __forceinline__ void put_row_pairs_mem(uint32_t* st, uint32_t q, const uint32_t* src, const uint2* lut)
+{
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {                             // pair k = bytes 3,2 (k even) or 1,0 (k odd) of word k/2
+        const uint32_t w  = hash4(src[k >> 1]);
+        const uint32_t sh = (k & 1) ? 0u : 16u;
+        const uint2 e0 = lut[(w >> (sh + 8u)) & 255u];
+        const uint2 e1 = lut[(w >> sh) & 255u];
+        put_bits64(st, q, ((uint64_t)e0.x << e1.y) | e1.x, e0.y + e1.y);
+        q += e0.y + e1.y;
     }
 }
 
@@ -509,10 +542,12 @@ __device__ __forceinline__ void load_tile(const EncodeParams& p, uint32_t tile, 
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     if (full) {
-        const u32x4* src = (const u32x4*)p.in + ((uint64_t)tile * kTileVec + (uint32_t)(wave * kRows * 64 + lane));
+        // scalar 64-bit tile base + a 32-bit per-lane offset (no per-lane 64-bit pointer kept alive across the loop)
+        const char* base = (const char*)p.in + (uint64_t)tile * (uint64_t)(kTileWords * 4);
+        const uint32_t off = (uint32_t)(wave * kRows * 64 + lane) * 16u;
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
-            const u32x4 t = __builtin_nontemporal_load(src + r * 64);
+            const u32x4 t = __builtin_nontemporal_load((const u32x4*)(base + off + (uint32_t)r * 1024u));
             raw[r] = make_uint4(t.x, t.y, t.z, t.w);
         }
     } else {
@@ -539,10 +574,10 @@ __device__ __forceinline__ int valid_words(const EncodeParams& p, uint64_t wbase
 __device__ __forceinline__ void finish_tile(const EncodeParams& p, Smem& sm, uint64_t tile, uint32_t par, int tid)
 {
     const TileState& ts = sm.ts[par];
-    const uint64_t P = ts.prefix;
-    const uint32_t T = ts.bits;
+    const uint64_t P = uni64(ts.prefix);
+    const uint32_t T = uni(ts.bits);
     const bool last = (tile == p.num_tiles - 1);
-    const uint32_t* sb = sm.ring + ts.start;
+    const uint32_t* sb = sm.ring + uni(ts.start);
     if (p.offsets && tid < kSegsPerTile && !HVLC_DBG(p, kDbgNoOffsets)) {
         const uint64_t seg = tile * kSegsPerTile + (uint64_t)tid;
         if (seg < p.num_segs) p.offsets[seg] = P + ts.seg_rel[tid];
@@ -557,7 +592,7 @@ __device__ __forceinline__ void finish_tile(const EncodeParams& p, Smem& sm, uin
     uint32_t nown = (s + T) >> 5;
     if (last) nown = ((s + T + 31u) >> 5) + ((((s + T) & 31u) == 0u) ? 1u : 0u);
     store_words(p, sb, s, P >> 5, nown, tid);
-    if (!(ts.flags & kTsEarlyTail) && tid == 0) {
+    if (!(uni(ts.flags) & kTsEarlyTail) && tid == 0) {
         const uint32_t own  = extract_tail(sb + 1, T);
         const uint32_t tail = T >= 31u ? own : (((ts.pred_tail << T) | own) & 0x7fffffffu);
         st_word(&p.recs[tile + 1].tail, kValid32 | tail);
@@ -649,7 +684,7 @@ struct RingCtl {
 __device__ __forceinline__ uint32_t ring_place(const RingCtl& c, const Smem& sm, uint32_t need, uint32_t n_stored)
 {
     if (c.n_packed == n_stored) return 0u;                                 // empty (need <= kRingWords is the caller's business)
-    const uint32_t tail = sm.ts[n_stored % kMaxIn].start;                  // oldest tile still in the ring
+    const uint32_t tail = uni(sm.ts[n_stored % kMaxIn].start);             // oldest tile still in the ring
     if (c.head > tail) {
         if (c.head + need <= kRingWords) return c.head;
         return need <= tail ? 0u : kRingWords;
@@ -665,17 +700,17 @@ __device__ __forceinline__ bool drain_step(const EncodeParams& p, Smem& sm, Data
 {
     const bool st_old = c.n_stored < limit && c.n_stored < c.n_res;
     const uint32_t ss = c.n_stored % kMaxIn;
-    if (st_old) finish_tile(p, sm, sm.tq[c.n_stored % kTq], ss, tid);
+    if (st_old) finish_tile(p, sm, uni(sm.tq[c.n_stored % kTq]), ss, tid);
     else        __builtin_amdgcn_s_sleep(8);
     bar.sync(sm, lane);
-    if (st_old) zero_words(sm.ring + sm.ts[ss].start, sm.ts[ss].need / 4u, tid);
+    if (st_old) zero_words(sm.ring + uni(sm.ts[ss].start), uni(sm.ts[ss].need) / 4u, tid);
     if (tid == 0) {
         sm.n_res_snap = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         sm.abort_snap = __hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     bar.sync(sm, lane);
-    if (sm.abort_snap) return false;
-    c.n_res = sm.n_res_snap;
+    if (uni(sm.abort_snap)) return false;
+    c.n_res = uni(sm.n_res_snap);
     if (st_old) ++c.n_stored;
     return true;
 }
@@ -707,7 +742,7 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
                               ring_place(c, sm, c.last_need, c.n_stored + (do_store ? 1u : 0u)) < kRingWords;   // is like the last one,
                                                                                                  // and with what this iteration frees)
         const uint32_t sp = c.n_packed % kMaxIn, ss = c.n_stored % kMaxIn;
-        const uint32_t cur = sm.tq[c.n_packed % kTq];                            // meaningful when have_raw
+        const uint32_t cur = uni(sm.tq[c.n_packed % kTq]);                       // meaningful when have_raw
         STAMP_COUNT(8, 1); STAMP_COUNT(9, can_pack ? 1 : 0); STAMP_COUNT(10, do_store ? 1 : 0);
         STAMP_COUNT(11, (!can_pack && !do_store) ? 1 : 0);
 
@@ -716,22 +751,35 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
         uint32_t tot[kRows], excl[kRows], rowbase[kRows];
         STAMP(0);
         if (do_store) {
-            const uint32_t st_tile = sm.tq[c.n_stored % kTq];
+            const uint32_t st_tile = uni(sm.tq[c.n_stored % kTq]);
             TL(p, st_tile, 5, tid == 0);
             finish_tile(p, sm, st_tile, ss, tid);
         }
         STAMP(1);
         if (can_pack) {
-            const bool full = cur < p.num_full_tiles;
             uint32_t wavetot = 0;
+            if (cur < p.num_full_tiles) {
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) encode16<true>(raw[r], 4, sm.lut, acc[r], tot[r]);
+            } else {
+                // the one tile the input ends in: bit counts only, the general path packs it (cold code)
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) {
+                    const uint64_t wbase = (uint64_t)cur * kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
+                    const int nv = valid_words(p, wbase);
+                    const uint32_t wd[4] = { raw[r].x, raw[r].y, raw[r].z, raw[r].w };
+                    uint32_t t = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < nv) {
+                            const uint32_t h = hash4(wd[k]);
+                            t += sm.lut[h >> 24].y + sm.lut[(h >> 16) & 255u].y + sm.lut[(h >> 8) & 255u].y + sm.lut[h & 255u].y;
+                        }
+                    tot[r] = t; acc[r] = 0;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < kRows; ++r) {
-                if (full) {
-                    encode16<true>(raw[r], 4, sm.lut, acc[r], tot[r]);
-                } else {
-                    const uint64_t wbase = (uint64_t)cur * kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
-                    encode16<false>(raw[r], valid_words(p, wbase), sm.lut, acc[r], tot[r]);
-                }
                 const uint32_t incl = wave_incl_scan(tot[r]);
                 excl[r]    = incl - tot[r];
                 rowbase[r] = wavetot;
@@ -741,7 +789,7 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
             STAMP(2);
         }
         if ((can_pack || !have_raw) && c.n_loaded < c.n_tix) {   // raw is dead or empty: its registers take the next drawn tile
-            const uint32_t nxt = sm.tq[c.n_loaded % kTq];
+            const uint32_t nxt = uni(sm.tq[c.n_loaded % kTq]);
             load_tile(p, nxt, nxt < p.num_full_tiles, wave, lane, raw);
             ++c.n_loaded;
         } else if (!can_pack && !do_store) {
@@ -753,12 +801,12 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
 
         // ---------------- phase Y ----------------
         bool release = do_store;                           // every wave is past its part of the store: clear its words; they
-        if (release) zero_words(sm.ring + sm.ts[ss].start, sm.ts[ss].need / 4u, tid);   // count as free after the next barrier
+        if (release) zero_words(sm.ring + uni(sm.ts[ss].start), uni(sm.ts[ss].need) / 4u, tid);   // count as free after the next barrier
         bool slow = false;
         if (can_pack) {
             uint32_t T = 0, wavebase = 0, clast = 0;
 #pragma unroll
-            for (int w2 = 0; w2 < kDataWaves; ++w2) { clast = sm.wave_tot[w2]; if (w2 < wave) wavebase += clast; T += clast; }
+            for (int w2 = 0; w2 < kDataWaves; ++w2) { clast = uni(sm.wave_tot[w2]); if (w2 < wave) wavebase += clast; T += clast; }
             if (tid == 0) {
                 if (cur != p.stall_tile) st_word(&p.bits32[cur], kValid32 | T);   // publish before anything else
                 TL(p, cur, 0, true);
@@ -766,7 +814,7 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
                 __hip_atomic_store(&sm.n_bits_pub, c.n_packed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             const uint32_t need = (((T + 31u) >> 5) + 2u + 3u) & ~3u;  // carry word + data + the word store_words reads ahead
-            slow = need > kRingWords;                        // fits no ring: general path, once the ring is empty
+            slow = need > kRingWords || cur >= p.num_full_tiles;   // fits no ring, or the partial last tile: general path, once the ring is empty
             uint32_t start = 0;
             if (!slow) {
                 // rare: the tile is bigger than predicted and the ring has no room yet -- store older tiles until it has
@@ -792,20 +840,23 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
             }
             if (!slow) {
                 uint32_t* const st = sm.ring + start + 1;
+                uint32_t big = 0;                            // rows of this lane with more than 64 bits (rare)
 #pragma unroll
                 for (int r = 0; r < kRows; ++r) {
                     const uint32_t q = wavebase + rowbase[r] + excl[r];
                     if (HVLC_DBG(p, kDbgNoPack)) { if (acc[r] == 0x123456789ull) st[q & 1023u] = tot[r]; continue; }
-                    if (tot[r] <= 64u) {
-                        put_bits64(st, q, acc[r], tot[r]);
-                    } else {                               // rare: re-read this lane's 16 bytes (L2) and go pairwise
-                        const uint64_t wbase = (uint64_t)cur * kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
-                        const uint32_t* in32 = (const uint32_t*)p.in;
-                        const int n = valid_words(p, wbase);
-                        uint32_t w[4];
+                    const bool fits = tot[r] <= 64u;
+                    put_bits64_flat(st, q, fits ? acc[r] : 0ull, fits ? tot[r] : 0u);
+                    big |= fits ? 0u : (1u << r);
+                }
+                if (__any(big != 0u)) {                      // cold: re-read such a lane-row (L2) and pack it pairwise
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) w[k] = k < n ? in32[wbase + k] : 0u;
-                        put_row_pairs(st, q, w, n, sm.lut);
+                    for (int r = 0; r < kRows; ++r) {
+                        if ((big >> r) & 1u) {
+                            const char* base = (const char*)p.in + (uint64_t)cur * (uint64_t)(kTileWords * 4);
+                            put_row_pairs_mem(st, wavebase + rowbase[r] + excl[r],
+                                              (const uint32_t*)(base + (uint32_t)((wave * kRows + r) * 64 + lane) * 16u), sm.lut);
+                        }
                     }
                 }
                 if (early_tail && wave == kDataWaves - 1 && lane == 0)   // same-wave LDS ops complete in order
@@ -823,8 +874,8 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
         STAMP(6);
         bar.sync(sm, lane);                                                   // data barrier 2
         STAMP(7);
-        if (sm.abort_snap) return;                        // uniform: one thread sampled the flag before the barrier
-        c.n_res = sm.n_res_snap; c.n_tix = sm.n_tix_snap; c.n_final = sm.n_final_snap;
+        if (uni(sm.abort_snap)) return;                   // uniform: one thread sampled the flag before the barrier
+        c.n_res = uni(sm.n_res_snap); c.n_tix = uni(sm.n_tix_snap); c.n_final = uni(sm.n_final_snap);
         if (release) ++c.n_stored;
         if (c.n_packed == c.n_stored) c.head = 0;         // empty ring: start over at word 0
 
@@ -873,6 +924,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
     uint32_t til[kMaxIn];               // tile a slot holds (tile n of the workgroup uses slot n % kMaxIn)
 #pragma unroll
     for (int s = 0; s < kMaxIn; ++s) { act[s] = false; done[s] = false; til[s] = 0; }
+    uint32_t rec_off = (uint32_t)(lane & 3) * 4u;   // per lane: what poll_round() reads (record 0 until a slot is started)
     uint32_t n_started = 0, n_done = 0; // tiles whose record is being polled / handed to the data waves
     uint32_t n_duty = 0;                // tiles already checked for the group-leader role
     LeaderDuty d;
@@ -913,14 +965,10 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
         uint32_t bv = kValid32;
         if (d.active && !d.have_bits && (uint32_t)lane < d.n)
             bv = __hip_atomic_load(&p.bits32[(uint64_t)d.g * kGroupTiles + (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const void* a[kMaxSlots];
         uint32_t pv;                     // lanes 0-23: the records of the tiles in flight; lanes 32-47: the leader's window
-#pragma unroll
-        for (int s = 0; s < kMaxSlots; ++s)
-            a[s] = &p.recs[(s < kMaxIn && act[s < kMaxIn ? s : 0]) ? (uint64_t)til[s < kMaxIn ? s : 0] : 0ull];
         if (d.active && !d.win_done) {
             const int32_t c0 = d.j & ~7;
-            pv = poll_round<true>(a, p.group_desc + c0, lane);
+            pv = poll_round<true>(p, rec_off, p.group_desc + c0, lane);
             bool stop = false;
 #pragma unroll
             for (int i = 7; i >= 0; --i) {
@@ -938,7 +986,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             }
             if (!d.win_done && d.j < 0) d.win_done = true;                // walked down to the start of the stream
         } else {
-            pv = poll_round<false>(a, nullptr, lane);
+            pv = poll_round<false>(p, rec_off, nullptr, lane);
         }
 
         // draw the next tile once the data waves are within two tiles of the last one drawn; the atomic is issued
@@ -962,7 +1010,9 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
                     if (lane == 0) {
                         sm.ts[s].prefix    = P & kValMask;
                         sm.ts[s].pred_tail = tl & 0x7fffffffu;
-                        sm.ring[sm.ts[s].start] = tl & 0x7fffffffu;             // the carry word of the packed tile
+                        // the carry word of the packed tile (a tile on the general path owns no ring words: it takes
+                        // the carry from pred_tail)
+                        if (sm.ts[s].need != 0u) sm.ring[sm.ts[s].start] = tl & 0x7fffffffu;
                     }
                     TL(p, til[s], 4, lane == 0);
                     done[s] = true;
@@ -1019,6 +1069,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
 #pragma unroll
             for (int s = 0; s < kMaxIn; ++s)
                 if ((uint32_t)s == sl) { act[s] = true; done[s] = false; til[s] = t; }
+            if ((uint32_t)(lane >> 2) == sl) rec_off = t * (uint32_t)sizeof(TileRec) + (uint32_t)(lane & 3) * 4u;
             TL(p, t, 1, lane == 0);
             ++n_started;
             progress = true;

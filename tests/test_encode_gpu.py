@@ -320,6 +320,19 @@ def test_timeout_is_reported_not_a_hang(golden, monkeypatch):
     e3.close()
 
 
+@pytest.mark.parametrize("extra_words", [1, 1234, 7167])
+def test_partial_last_tile_behind_a_busy_ring(enc, golden, extra_words):
+    """The tile the input ends in takes the general path while its workgroup still holds packed tiles in the
+    staging ring (regression: its carry word must not be written into another tile's ring words)."""
+    n = 3000 * 7168 + extra_words                               # ~82 MiB: every workgroup has several tiles
+    x = np.tile(golden["period"], (4 * n) // golden["period"].size + 1)[: 4 * n].view(np.uint32)
+    d_tab = enc.table_to_device(golden["cw"], golden["cl"])
+    for _ in range(3):
+        o, offs, bits = enc.encode(_dev(x), d_tab, max_len=21)
+        ref, rbits = O.encode(x, golden["cw"], golden["cl"])
+        assert bits == rbits and torch.equal(o[: bits // 32 + 1].cpu(), torch.from_numpy(ref.view(np.int32)))
+
+
 @pytest.mark.parametrize("factor", [2, 4])
 def test_oversubscribed_grid_still_encodes(golden, monkeypatch, factor):
     """Tiles are drawn by running workgroups only, so a grid that is NOT co-resident (forced to 2x / 4x what
