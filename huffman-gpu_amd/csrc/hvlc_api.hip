@@ -116,13 +116,13 @@ int env_int(const char* name, int dflt)
     return (v && *v) ? atoi(v) : dflt;
 }
 
-// Persistent grid: every workgroup must be resident at once (see hvlc_device.hip.h).  The occupancy
-// API is advisory: it can over-report for SGPR-heavy kernels on ROCm 7.2 (CDNA4 guide), and it counts wave
-// slots per CU, while a workgroup whose wave count is not a multiple of 4 puts one wave more on one SIMD
-// than on the others, starting from a SIMD that rotates with the dispatch history.  Observed on MI355X:
-// four 5-wave workgroups per CU (20 of 24 slots at 80 VGPRs) are resident on a fresh device but NOT right
-// after an aborted launch, when the doubled-up SIMDs coincide (8 waves > 6 slots).  So the grid is limited
-// to what fits under the WORST placement: every workgroup's largest per-SIMD share on the same SIMD.
+// Persistent grid, sized to what is resident at once.  Correctness no longer depends on it (tiles are drawn
+// by running workgroups only, hvlc_device.hip.h), but workgroups queued behind the resident ones would only
+// find the ticket counters exhausted, so more than fits buys nothing.  The occupancy API is advisory: it can
+// over-report for SGPR-heavy kernels on ROCm 7.2 (CDNA4 guide), and it counts wave slots per CU, while a
+// workgroup whose wave count is not a multiple of 4 puts one wave more on one SIMD than on the others.  The
+// grid is therefore limited to what fits under the WORST placement; the 8-wave encoder workgroup (two waves
+// per SIMD) makes the placement irrelevant: three workgroups per CU at 80 VGPRs and 52 KiB of LDS each.
 template <typename K>
 int pick_blocks_per_cu(hvlc_ctx* c, K kernel, int block_threads, size_t dyn_lds, int cap)
 {

@@ -10,36 +10,39 @@
 // Decomposition (all names follow the reference's domain):
 //   segment  256 input words = 1024 symbols  = ONE WAVE-ROW (64 lanes x 16 bytes);
 //            the reference's block (main_test_cu.cu:43); unit of out_offsets
-//   tile     12 segments = 12 KiB            = one pass of a workgroup's 3 data waves;
+//   tile     28 segments = 28 KiB            = one pass of a workgroup's 7 data waves;
 //            data wave w owns the tile's segments 4w..4w+3 (4 KiB contiguous)
-//   group    64 tiles = 768 KiB              = unit of the second scan level
+//   group    64 tiles = 1.75 MiB             = unit of the second scan level
 //
-// Workgroup = 3 DATA waves + 1 SCOUT wave (one wave per SIMD).  Data waves, per
-// tile: (1) coalesced non-temporal dwordx4 loads (next tile prefetched);
-// (2) per-lane LDS table lookups and 64-bit concatenation of 16 symbols;
-// (3) wave64 DPP prefix scan of the bit lengths per segment, wave totals through
-// LDS; (4) the tile's bit count is PUBLISHED (8-byte self-validating granule,
-// relaxed agent-scope store); (5) "pabio": each lane ORs its <=64 bits into one
-// of kSlots LDS staging slots with <=3 ds_or_b32 at TILE-LOCAL bit positions (so
-// packing does not wait for the global offset); (7) once the scout has resolved
-// the tile, the slot is funnel-shifted (v_alignbit_b32) by offset%32 and stored
-// with coalesced dword stores; segment offsets are written as uint64.
-// Scout wave: (6) resolves every packed tile's global bit offset by a two-level
-// decoupled look-back (in-group tile granules; group leaders walk 64 group
-// granules per hop, other tiles wait for the previous group's inclusive prefix)
-// and fetches the <=31 carry bits of the predecessor; one Resolver per slot is in
-// flight.  The scout exists because VMEM retires in order per wave: a data wave
-// polling granules would drain its own prefetch and stores first.
+// Workgroup = 7 DATA waves + 1 SCOUT wave (two waves per SIMD), three workgroups per CU.
+// Data waves, per tile: (1) coalesced non-temporal dwordx4 loads (next tile
+// prefetched); (2) per-lane LDS table lookups (one SDWA op per address) and 64-bit
+// concatenation of 16 symbols; (3) wave64 DPP prefix scan of the bit lengths per
+// segment, wave totals through LDS; (4) the tile's bit count is PUBLISHED (one
+// self-validating word, relaxed agent-scope store); (5) "pabio": each lane ORs its
+// <=64 bits into the workgroup's LDS staging ring with 3 ds_or_b32 at TILE-LOCAL
+// bit positions (so packing does not wait for the global offset); (7) once the
+// scout has seen the tile's global bit offset, the tile's ring words are
+// funnel-shifted (v_alignbit_b32) by offset%32 and stored with coalesced dword
+// stores; segment offsets are written as uint64.
+// Scout wave: draws the workgroup's tiles from ticket counters, and (6) polls ONE
+// 16-byte record per tile in flight (global offset + the predecessor's <=31 carry
+// bits).  The offsets come from a two-level scan: the scout of the LAST tile of each
+// 64-tile group reads the group's 64 bit counts, publishes the group aggregate,
+// walks the group granules down to the nearest inclusive prefix and writes the
+// offsets of all 64 tiles into their records.  The scout exists because VMEM
+// retires in order per wave: a data wave polling other workgroups' words would
+// drain its own prefetch and stores first.
 //
-// Forward progress: the grid is PERSISTENT and sized to be co-resident (host side,
-// hvlc_api.hip); tile t is processed by workgroup t % gridDim.x, tiles of one
-// workgroup in increasing order, so every tile a wait depends on belongs to a
-// running workgroup whatever the dispatch order or XCD placement.  Every wait is
-// bounded (s_memrealtime) and ends in HVLC_ERR_TIMEOUT instead of a hang.
-// Inter-workgroup data are single 8-byte granules carrying their own valid bit,
-// written once and read with relaxed agent-scope (sc1) accesses -- the form the
-// CDNA4 guide lists as needing no release/acquire fence -- and zeroed before each
-// launch by k_prepare.
+// Forward progress: tiles are drawn only by RUNNING workgroups (dynamic tickets, 64
+// classes so that a workgroup never holds two tiles of one group), workgroups work
+// through their tiles in increasing order, and a tile depends only on tiles with
+// lower numbers plus its group's last tile -- so the encoder finishes whatever part
+// of the grid is resident.  Every wait is still bounded (s_memrealtime) and ends in
+// HVLC_ERR_TIMEOUT instead of a hang.  Inter-workgroup data are single naturally
+// aligned words carrying their own valid bit, written once and read with relaxed
+// agent-scope (sc1) accesses -- the form the CDNA4 guide lists as needing no
+// release/acquire fence -- and zeroed before each launch by k_prepare.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -895,18 +898,18 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
 }
 
 // ------------------------------------------------------------------------------------------------
-// SCOUT wave: everything that crosses workgroups.  It is a SCALAR program: what a tile waits for is one
-// 16-byte record (TileRec), polled with one s_load per tile in flight, all of a round's loads in one asm
-// block (one round trip per round).  Vector-memory operations retire in order per wave and queue behind
-// the CU's streaming loads, so neither the data waves nor a vector poll loop should do this.
+// SCOUT wave: everything that crosses workgroups.  Its decisions are scalar code: what a tile waits for is
+// one 16-byte record (TileRec); one vector sc1 load per round fetches the records of all tiles in flight
+// (and a group leader's window), v_readlane moves what is needed into SGPRs.
 //
 // Offsets come from a two-level scan over the granules: the LAST tile of every 64-tile group is the
 // group's leader.  Its scout (LeaderDuty) reads the 64 bit counts of the group (one vector load),
-// publishes the group's aggregate, walks the group granules downwards (8 per scalar load) to the nearest
+// publishes the group's aggregate, walks the group granules downwards (8 per round) to the nearest
 // inclusive prefix, publishes the group's inclusive prefix and then the global offset of EVERY tile of the
-// group (one 64-lane store into the records).  So a tile's offset costs its own scout one scalar poll, and
-// the chain packed -> leader -> records is three hand-offs whatever the input size.
-// The scout free-runs: it takes no part in the data waves' barrier and hands results over through LDS.
+// group (one 64-lane store into the records).  So a tile's offset costs its own scout one poll per round,
+// and the chain packed -> leader -> records is three hand-offs whatever the input size.
+// The scout also draws the workgroup's tiles (RingCtl).  It free-runs: it takes no part in the data waves'
+// barrier and hands results over through LDS.
 // ------------------------------------------------------------------------------------------------
 static_assert(kMaxIn <= kMaxSlots, "the scout polls at most kMaxSlots records per round");
 struct LeaderDuty {

@@ -54,7 +54,7 @@ typedef enum hvlc_status {
 typedef struct hvlc_ctx hvlc_ctx;   /* workspace: replaces preallocBlockSums/deallocBlockSums (scan.cu:67,98) */
 
 /* Create / destroy a context bound to `device`.  max_words sizes the workspace
- * (16 B per 12 KiB of input); it grows on demand if a later call is larger. */
+ * (20 B per 28 KiB of input); it grows on demand if a later call is larger. */
 int hvlc_create(hvlc_ctx** ctx, int device, uint64_t max_words);
 int hvlc_destroy(hvlc_ctx* ctx);
 
