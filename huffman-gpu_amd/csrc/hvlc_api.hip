@@ -474,6 +474,41 @@ int hvlc_rebase_offsets_dev(hvlc_ctx* c, uint64_t* d_offsets, uint64_t n,
     return HVLC_OK;
 }
 
+int hvlc_merge_shard(hvlc_ctx* c, const uint32_t* d_src_bits, uint64_t nbits, uint32_t* d_dst_bits,
+                     uint64_t dst_capacity_words, uint64_t dst_bit_offset, void* stream)
+{
+    if (!c || (nbits && (!d_src_bits || !d_dst_bits))) return HVLC_ERR_ARG;
+    if (nbits == 0) return HVLC_OK;
+    const uint64_t last_word = (dst_bit_offset + nbits - 1) >> 5;
+    if (last_word >= dst_capacity_words) return HVLC_ERR_CAPACITY;
+    HVLC_HIP(c, hipSetDevice(c->device));
+    const uint64_t nd = (((uint32_t)dst_bit_offset & 31u) + nbits + 31u) >> 5;
+    uint64_t grid = (nd + kThreads - 1) / kThreads;
+    const uint64_t cap = (uint64_t)c->cus * 32;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_merge_shard, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
+                       d_src_bits, nbits, d_dst_bits, dst_bit_offset);
+    HVLC_HIP(c, hipGetLastError());
+    return HVLC_OK;
+}
+
+int hvlc_decode(hvlc_ctx* c, const uint32_t* d_bits, uint64_t total_bits, const uint64_t* d_offsets,
+                const uint32_t* d_codewords, const uint32_t* d_codewordlens, uint32_t* d_out_words,
+                uint64_t num_words, void* stream)
+{
+    if (!c || !d_codewords || !d_codewordlens || (num_words && (!d_bits || !d_offsets || !d_out_words))) return HVLC_ERR_ARG;
+    if (num_words == 0) return HVLC_OK;
+    HVLC_HIP(c, hipSetDevice(c->device));
+    const uint64_t segs = hvlc_num_segments(num_words);
+    uint64_t grid = (segs + kThreads - 1) / kThreads;
+    const uint64_t cap = (uint64_t)c->cus * 8;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
+                       d_bits, total_bits, d_offsets, segs, d_codewords, d_codewordlens, d_out_words, num_words);
+    HVLC_HIP(c, hipGetLastError());
+    return HVLC_OK;
+}
+
 int hvlc_gen_symbols(hvlc_ctx* c, uint8_t* d_out, uint64_t n_bytes, uint64_t seed,
                      uint64_t first_draw, const uint32_t* d_cdf32, void* stream)
 {

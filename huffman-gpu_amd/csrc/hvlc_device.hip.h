@@ -1273,6 +1273,94 @@ __global__ void __launch_bounds__(kThreads) k_rebase_dev(uint64_t* offs, uint64_
 }
 
 // ---------------------------------------------------------------------------------------------
+// SURVEY.md section 8(f) #1 -- seam merge: funnel-shift copy of a whole stream (a shard's) to an arbitrary bit
+// position of the job's contiguous stream; pack2 (pack_kernels.cu:19-52) generalised from 256-word blocks to
+// shards.  Destination word j takes bits from source words j-1 and j (v_alignbit_b32).  Interior words are
+// stored; the first and last destination words, which the neighbouring shards may also write, are merged with
+// an atomic OR (they must be zero before the first merge).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_merge_shard(const uint32_t* __restrict__ src, uint64_t nbits,
+                                                          uint32_t* __restrict__ dst, uint64_t dst_bit_offset)
+{
+    const uint32_t s  = (uint32_t)dst_bit_offset & 31u;
+    const uint64_t w0 = dst_bit_offset >> 5;
+    const uint64_t nd = (s + nbits + 31u) >> 5;                   // destination words touched
+    const uint64_t ns = (nbits + 31u) >> 5;                       // source words holding bits (zero padded by the encoder)
+    for (uint64_t k = (uint64_t)blockIdx.x * kThreads + threadIdx.x; k < nd; k += (uint64_t)gridDim.x * kThreads) {
+        const uint32_t hi = (k >= 1 && k - 1 < ns) ? src[k - 1] : 0u;
+        const uint32_t lo = k < ns ? src[k] : 0u;
+        uint32_t v = s ? __builtin_amdgcn_alignbit(hi, lo, s) : lo;      // ({hi,lo} >> s): hi's low s bits, then lo's top bits
+        if (k == nd - 1) {                                                // bits past the end of the shard are not ours
+            const uint32_t used = (uint32_t)((s + nbits) & 31u);
+            if (used) v &= ~0u << (32u - used);
+        }
+        if (k == 0 || k == nd - 1) { if (v) atomicOr(&dst[w0 + k], v); }
+        else dst[w0 + k] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SURVEY.md section 8(f) #3 -- decoder (the reference has none; it exists to prove round trips).  One thread per
+// 1024-byte segment, starting at the segment's bit offset.  Codes of up to kDecBits bits resolve with one LDS
+// lookup of the next kDecBits stream bits; longer ones by a linear search over the (few) long codes.
+// Precondition: a prefix-free table; symbols with length 0 cannot be decoded.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDecBits = 12;
+__global__ void __launch_bounds__(kThreads) k_decode(const uint32_t* __restrict__ bits, uint64_t total_bits,
+                                                     const uint64_t* __restrict__ offsets, uint64_t num_segs,
+                                                     const uint32_t* __restrict__ cw, const uint32_t* __restrict__ cl,
+                                                     uint32_t* __restrict__ out, uint64_t num_words)
+{
+    __shared__ uint16_t fast[1 << kDecBits];         // (symbol << 8) | length, 0 = a longer code
+    __shared__ uint32_t lcode[256];                  // long codes, left-aligned in 32 bits
+    __shared__ uint8_t  llen[256], lsym[256];
+    __shared__ uint32_t nlong;
+    for (int i = threadIdx.x; i < (1 << kDecBits); i += kThreads) fast[i] = 0;
+    if (threadIdx.x == 0) nlong = 0;
+    __syncthreads();
+    {
+        const uint32_t len = cl[threadIdx.x], c = cw[threadIdx.x];
+        if (len >= 1 && len <= (uint32_t)kDecBits) {
+            const uint32_t base = c << (kDecBits - len), n = 1u << (kDecBits - len);
+            for (uint32_t i = 0; i < n; ++i) fast[base + i] = (uint16_t)((threadIdx.x << 8) | len);
+        } else if (len > (uint32_t)kDecBits && len <= 31u) {
+            const uint32_t k = atomicAdd(&nlong, 1u);
+            lcode[k] = c << (32u - len); llen[k] = (uint8_t)len; lsym[k] = (uint8_t)threadIdx.x;
+        }
+    }
+    __syncthreads();
+    const uint64_t total_words = (total_bits >> 5) + 1;
+    for (uint64_t seg = (uint64_t)blockIdx.x * kThreads + threadIdx.x; seg < num_segs; seg += (uint64_t)gridDim.x * kThreads) {
+        uint64_t pos = offsets[seg];                 // next bit to read
+        const uint64_t w_first = seg * kSegWords;
+        const uint64_t w_end = w_first + kSegWords < num_words ? w_first + kSegWords : num_words;
+        for (uint64_t w = w_first; w < w_end; ++w) {
+            uint32_t word = 0;
+#pragma unroll 1
+            for (int b = 0; b < 4; ++b) {
+                // the next 32 stream bits, left-aligned
+                const uint64_t wi = pos >> 5; const uint32_t sh = (uint32_t)pos & 31u;
+                const uint32_t hi = wi < total_words ? bits[wi] : 0u;
+                const uint32_t lo = wi + 1 < total_words ? bits[wi + 1] : 0u;
+                const uint32_t win = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
+                uint32_t e = fast[win >> (32 - kDecBits)];
+                uint32_t sym = e >> 8, len = e & 255u;
+                if (len == 0u) {                     // a long code (or an invalid stream: then symbol 0, one bit)
+                    len = 1u; sym = 0u;
+                    for (uint32_t k = 0; k < nlong; ++k) {
+                        const uint32_t L = llen[k];
+                        if (((win ^ lcode[k]) >> (32u - L)) == 0u) { len = L; sym = lsym[k]; break; }
+                    }
+                }
+                pos += len;
+                word = (word << 8) | sym;            // most significant byte first (cpuencode.cpp:28)
+            }
+            out[w] = word;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Harness utilities: synthetic symbol generator and byte histogram.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)

@@ -31,7 +31,7 @@ EXPORTS = [
     "hvlc_create", "hvlc_destroy", "hvlc_out_capacity_words", "hvlc_num_segments", "hvlc_encode",
     "hvlc_finish", "gpu_vlc_encode", "hvlc_segment_bits", "hvlc_exclusive_scan", "hvlc_rebase_offsets",
     "hvlc_rebase_offsets_dev", "hvlc_profile_begin", "hvlc_profile_collect",
-    "hvlc_gen_symbols", "hvlc_histogram", "hvlc_get_launch_info", "hvlc_last_hip_error",
+    "hvlc_gen_symbols", "hvlc_histogram", "hvlc_merge_shard", "hvlc_decode", "hvlc_get_launch_info", "hvlc_last_hip_error",
     "hvlc_status_string", "hvlc_version",
 ]
 
@@ -221,6 +221,22 @@ class Encoder:
         _check(lib().hvlc_rebase_offsets_dev(self._ctx, C.c_void_p(d_offsets.data_ptr()), d_offsets.numel(),
                                              C.c_void_p(d_shard_totals.data_ptr()), int(rank), _stream_ptr(None)),
                "hvlc_rebase_offsets_dev")
+
+    def merge_shard(self, d_src_bits, nbits, d_dst_bits, dst_bit_offset):
+        """Seam merge (SURVEY 8(f)#1): copy `nbits` bits of a shard stream to bit `dst_bit_offset` of d_dst_bits."""
+        _check(lib().hvlc_merge_shard(self._ctx, C.c_void_p(d_src_bits.data_ptr()), C.c_uint64(int(nbits)),
+                                      C.c_void_p(d_dst_bits.data_ptr()), C.c_uint64(d_dst_bits.numel()),
+                                      C.c_uint64(int(dst_bit_offset)), _stream_ptr(None)), "hvlc_merge_shard")
+
+    def decode(self, d_bits, total_bits, d_offsets, d_table, num_words):
+        """Decoder (SURVEY 8(f)#3): returns an int32 tensor of `num_words` words."""
+        import torch
+        out = torch.empty(int(num_words), dtype=torch.int32, device=d_bits.device)
+        _check(lib().hvlc_decode(self._ctx, C.c_void_p(d_bits.data_ptr()), C.c_uint64(int(total_bits)),
+                                 C.c_void_p(d_offsets.data_ptr()), C.c_void_p(d_table.data_ptr()),
+                                 C.c_void_p(d_table.data_ptr() + 1024), C.c_void_p(out.data_ptr()),
+                                 C.c_uint64(int(num_words)), _stream_ptr(None)), "hvlc_decode")
+        return out
 
     def profile_begin(self, max_launches):
         _check(lib().hvlc_profile_begin(self._ctx, int(max_launches)), "hvlc_profile_begin")

@@ -150,6 +150,25 @@ int hvlc_gen_symbols(hvlc_ctx* ctx, uint8_t* d_out, uint64_t n_bytes, uint64_t s
 int hvlc_histogram(hvlc_ctx* ctx, const uint8_t* d_data, uint64_t n_bytes,
                    uint64_t* d_hist, void* stream);
 
+/* SURVEY.md section 8(f) #1 -- seam merge / contiguous stream materialisation.  Copies the `nbits` bits of a
+ * stream that starts at bit 0 of d_src_bits (a shard's output of hvlc_encode; may be P2P-mapped memory of a peer
+ * GPU) to bit position dst_bit_offset of d_dst_bits: what pack2 (pack_kernels.cu:19-52) does for 256-word
+ * blocks, for whole shards.  Interior destination words are overwritten; the first and the last one, which the
+ * neighbouring shards share, are merged with an atomic OR and must be ZERO before the first merge that touches
+ * them (zero-fill the seam words or all of d_dst_bits once).  Shards may be merged in any order, concurrently.
+ * Merging every shard at its base (hvlc_rebase_offsets[_dev]'s base) into a zeroed buffer of
+ * floor(total/32)+1 words reproduces cpu_vlc_encode's stream of the whole input. */
+int hvlc_merge_shard(hvlc_ctx* ctx, const uint32_t* d_src_bits, uint64_t nbits, uint32_t* d_dst_bits,
+                     uint64_t dst_capacity_words, uint64_t dst_bit_offset, void* stream);
+
+/* SURVEY.md section 8(f) #3 -- decoder (the reference has none; this one exists to prove round trips).
+ * Inverse of hvlc_encode for PREFIX-FREE tables in which every symbol that occurs has length >= 1: one thread per
+ * 1024-byte segment, started at d_offsets[segment].  Writes num_words words (4 symbols each, most significant byte
+ * first).  An invalid stream or table yields wrong symbols, never an out-of-bounds access. */
+int hvlc_decode(hvlc_ctx* ctx, const uint32_t* d_bits, uint64_t total_bits, const uint64_t* d_offsets,
+                const uint32_t* d_codewords, const uint32_t* d_codewordlens, uint32_t* d_out_words,
+                uint64_t num_words, void* stream);
+
 /* Introspection: launch geometry chosen for this device (grid, blocks per CU,
  * CUs) and the last HIP error code seen by this context. */
 int hvlc_get_launch_info(hvlc_ctx* ctx, int* grid_blocks, int* blocks_per_cu, int* compute_units);

@@ -209,3 +209,38 @@ uint64_t oracle_vlc_encode_mt(const uint32_t* indata, uint64_t num_elements,
     free(jobs); free(tids);
     return bits;
 }
+
+/* ---- bit-exact append (checker for hvlc_merge_shard) ------------------------------ */
+uint64_t oracle_bit_append(uint32_t* dst, uint64_t dst_bits, const uint32_t* src, uint64_t nbits)
+{
+    for (uint64_t i = 0; i < nbits; ++i) {
+        const uint32_t bit = (src[i >> 5] >> (31u - (uint32_t)(i & 31u))) & 1u;
+        const uint64_t d = dst_bits + i;
+        if (bit) dst[d >> 5] |= 1u << (31u - (uint32_t)(d & 31u));
+    }
+    return dst_bits + nbits;
+}
+
+/* ---- reference decoder (checker for hvlc_decode) ---------------------------------- */
+uint64_t oracle_vlc_decode(const uint32_t* bits, uint64_t start_bit, uint32_t* outdata, uint64_t num_elements,
+                           const uint32_t* codewords, const uint32_t* codewordlens)
+{
+    uint64_t pos = start_bit;
+    for (uint64_t w = 0; w < num_elements; ++w) {
+        uint32_t word = 0;
+        for (int b = 0; b < 4; ++b) {
+            uint32_t acc = 0, len = 0;
+            int found = -1;
+            while (found < 0 && len < 31u) {
+                acc = (acc << 1) | ((bits[pos >> 5] >> (31u - (uint32_t)(pos & 31u))) & 1u);
+                ++pos; ++len;
+                for (int s = 0; s < 256; ++s)
+                    if (codewordlens[s] == len && codewords[s] == acc) { found = s; break; }
+            }
+            if (found < 0) return ~(uint64_t)0;
+            word = (word << 8) | (uint32_t)found;
+        }
+        outdata[w] = word;
+    }
+    return pos - start_bit;
+}

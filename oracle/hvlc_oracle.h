@@ -69,6 +69,19 @@ void oracle_gen_symbols(uint8_t* out, uint64_t n_bytes, uint64_t seed,
 /* 256-bin byte histogram of a buffer (helper for table construction in tests). */
 void oracle_histogram(const uint8_t* data, uint64_t n_bytes, uint64_t* hist);
 
+/* SURVEY.md section 8(f) #1, checker for the seam merge: append the first nbits bits of src (uint32 words, bit 31
+ * first) to a stream that already holds dst_bits bits; dst words from the open word on must be zero or hold
+ * earlier appended bits.  What pack2 (pack_kernels.cu:34-50) does word by word, restated bit-exactly with
+ * 64-bit positions.  Returns the new bit count. */
+uint64_t oracle_bit_append(uint32_t* dst, uint64_t dst_bits, const uint32_t* src, uint64_t nbits);
+
+/* SURVEY.md section 8(f) #3, checker for the decoder (the reference has none): decode num_elements words
+ * (4 symbols each, most significant byte first) from a stream produced by oracle_vlc_encode with a prefix-free
+ * table, by matching the code of every symbol bit by bit.  Returns the number of bits consumed, or ~0 if no code
+ * matches. */
+uint64_t oracle_vlc_decode(const uint32_t* bits, uint64_t start_bit, uint32_t* outdata, uint64_t num_elements,
+                           const uint32_t* codewords, const uint32_t* codewordlens);
+
 /* FNV-1a 64-bit over bytes (fixture hashes). */
 uint64_t oracle_fnv1a64(const void* data, uint64_t n_bytes);
 

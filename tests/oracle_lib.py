@@ -46,6 +46,10 @@ def _load():
     lib.oracle_gen_symbols.restype = None
     lib.oracle_histogram.argtypes = [_u8p, C.c_uint64, _u64p]
     lib.oracle_histogram.restype = None
+    lib.oracle_bit_append.argtypes = [_u32p, C.c_uint64, _u32p, C.c_uint64]
+    lib.oracle_bit_append.restype = C.c_uint64
+    lib.oracle_vlc_decode.argtypes = [_u32p, C.c_uint64, _u32p, C.c_uint64, _u32p, _u32p]
+    lib.oracle_vlc_decode.restype = C.c_uint64
     lib.oracle_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
     lib.oracle_fnv1a64.restype = C.c_uint64
     lib.oracle_vlc_encode_mt.argtypes = [_u32p, C.c_uint64, _u32p, C.c_uint64, _u32p, _u32p,
@@ -131,6 +135,21 @@ def histogram(data_u8):
     h = np.zeros(256, dtype=np.uint64)
     lib().oracle_histogram(_ptr(d, _u8p), d.size, _ptr(h, _u64p))
     return h
+
+
+def bit_append(dst, dst_bits, src, nbits):
+    """Append the first nbits bits of src to the stream in dst (in place).  Returns the new bit count."""
+    assert dst.dtype == np.uint32 and src.dtype == np.uint32
+    return int(lib().oracle_bit_append(_ptr(dst, _u32p), int(dst_bits), _ptr(np.ascontiguousarray(src), _u32p), int(nbits)))
+
+
+def decode(bits, num_words, codewords, codewordlens, start_bit=0):
+    """CPU decoder (prefix-free table).  Returns (words, bits consumed)."""
+    cw, cl = _tables(codewords, codewordlens)
+    out = np.zeros(int(num_words), dtype=np.uint32)
+    used = int(lib().oracle_vlc_decode(_ptr(np.ascontiguousarray(bits), _u32p), int(start_bit), _ptr(out, _u32p),
+                                       int(num_words), _ptr(cw, _u32p), _ptr(cl, _u32p)))
+    return out, used
 
 
 def fnv1a64(arr):

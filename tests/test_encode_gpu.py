@@ -440,3 +440,78 @@ def test_general_path_large(enc):
     out, offs, bits = enc.encode(d_in, enc.table_to_device(cw, cl), max_len=8)
     assert bits == 8 * n
     _check_windows(enc, d_in, out, offs, bits, cw, cl, hist, 8, np.random.default_rng(2))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SURVEY.md section 8(f) "next" rows: seam merge (#1) and decoder (#3)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cuts", [(0.5,), (0.1, 0.6), (0.25, 0.5, 0.75), (0.001, 0.999)])
+def test_merge_shards_into_one_stream(enc, golden, cuts):
+    """Shards encoded independently (cut at segment multiples) and merged at their bases reproduce the
+    oracle's stream of the whole input word for word; merge order does not matter."""
+    x = np.tile(golden["period"], 24).view(np.uint32)[: 24 * 65536 - 4321]      # ~6 MiB, ragged
+    d_tab = enc.table_to_device(golden["cw"], golden["cl"])
+    ref, rbits = O.encode(x, golden["cw"], golden["cl"])
+    bounds = [0] + [int(c * x.size) // 256 * 256 for c in cuts] + [x.size]
+    parts = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        o, _, bits = enc.encode(_dev(x[a:b]), d_tab, max_len=21)
+        parts.append((o.clone(), bits))
+    bases = np.concatenate([[0], np.cumsum([b for _, b in parts])]).astype(np.uint64)
+    assert int(bases[-1]) == rbits
+    dst = torch.zeros(rbits // 32 + 1, dtype=torch.int32, device="cuda")
+    for i in reversed(range(len(parts))):                                       # any order
+        enc.merge_shard(parts[i][0], parts[i][1], dst, int(bases[i]))
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy().view(np.uint32), ref[: rbits // 32 + 1])
+
+
+@pytest.mark.gpu
+def test_merge_matches_oracle_append_at_odd_offsets(enc):
+    """Random bit strings appended at random bit positions: device merge == oracle_bit_append."""
+    rng = np.random.default_rng(7)
+    dst_ref = np.zeros(4096, dtype=np.uint32)
+    dst = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    pos = 0
+    for _ in range(40):
+        nbits = int(rng.integers(1, 3000))
+        src = rng.integers(0, 2**32, size=(nbits + 31) // 32, dtype=np.uint32)
+        if nbits % 32: src[-1] &= np.uint32((0xffffffff << (32 - nbits % 32)) & 0xffffffff)   # zero padded like the encoder's
+        enc.merge_shard(_dev(src), nbits, dst, pos)
+        pos = O.bit_append(dst_ref, pos, src, nbits)
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy().view(np.uint32), dst_ref)
+    with pytest.raises(hvlc.HvlcError):
+        enc.merge_shard(_dev(np.ones(4, np.uint32)), 128, dst, 4096 * 32 - 64)  # would run past the destination
+
+
+@pytest.mark.gpu
+def test_decode_round_trip_and_oracle_decoder(enc, golden):
+    """decode(encode(x)) == x on the device, and the device decoder agrees with the oracle's on a prefix."""
+    x = np.tile(golden["period"], 8).view(np.uint32)[: 8 * 65536 - 999]
+    d_tab = enc.table_to_device(golden["cw"], golden["cl"])
+    o, offs, bits = enc.encode(_dev(x), d_tab, max_len=21)
+    y = enc.decode(o, bits, offs, d_tab, x.size)
+    assert np.array_equal(y.cpu().numpy().view(np.uint32), x)
+    yo, _ = O.decode(o[: 4096].cpu().numpy().view(np.uint32), 1024, golden["cw"], golden["cl"])
+    assert np.array_equal(yo, x[:1024])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["H2.2", "H4.0", "H1.0"])
+def test_round_trip_at_full_size(name, golden):
+    """Size-independent property at BASELINE's full sizes: encode -> decode reproduces the 4 GiB input exactly
+    (tables with codes longer than the decoder's 12-bit fast table included)."""
+    from util import dist_weights, SEEDS
+    n = 4 << 30
+    e = hvlc.Encoder(0, n // 4)
+    d_in = e.gen_symbols(n, SEEDS[name], hvlc.cdf32_from_counts(dist_weights(name, golden["period"])))
+    hist = e.histogram(d_in).cpu().numpy().astype(np.uint64)
+    cw, cl = hvlc.huffman_table(hist)
+    d_tab = e.table_to_device(cw, cl)
+    o, offs, bits = e.encode(d_in, d_tab, max_len=int(cl.max()))
+    y = e.decode(o, bits, offs, d_tab, n // 4)
+    assert torch.equal(y.view(torch.uint8), d_in.view(torch.uint8))
+    del y, o, offs, d_in
+    e.close()

@@ -157,3 +157,27 @@ def test_differential_vs_compiled_reference(golden):
     o_ref, s_ref = O.ref_encode32(x, golden["cw"], golden["cl"])
     o_own, s_own = O.encode32(x, golden["cw"], golden["cl"])
     assert s_ref == s_own and np.array_equal(o_ref[: (s_ref + 3) // 4], o_own[: (s_ref + 3) // 4])
+
+
+def test_bit_append_reproduces_the_whole_stream(golden):
+    """SURVEY 8(f)#1 checker: appending the streams of shards (cut at segment multiples) bit-exactly gives the
+    stream of the whole input -- encoding is concatenative."""
+    x = np.tile(golden["period"], 3).view(np.uint32)[: 3 * 256 * 97 + 41]
+    ref, rbits = O.encode(x, golden["cw"], golden["cl"])
+    dst = np.zeros(rbits // 32 + 2, dtype=np.uint32)
+    pos = 0
+    for a, b in ((0, 256 * 10), (256 * 10, 256 * 57), (256 * 57, x.size)):
+        part, pbits = O.encode(x[a:b], golden["cw"], golden["cl"])
+        pos = O.bit_append(dst, pos, part, pbits)
+    assert pos == rbits and np.array_equal(dst[: rbits // 32 + 1], ref[: rbits // 32 + 1])
+
+
+def test_decoder_inverts_the_encoder(golden):
+    """SURVEY 8(f)#3 checker: decode(encode(x)) == x for the golden (prefix-free) table, also from a segment offset."""
+    x = golden["period"].view(np.uint32)[:2048]
+    ref, rbits = O.encode(x, golden["cw"], golden["cl"])
+    y, used = O.decode(ref, x.size, golden["cw"], golden["cl"])
+    assert used == rbits and np.array_equal(x, y)
+    _, offs, _ = O.segment_offsets(x, golden["cl"])
+    y3, _ = O.decode(ref, 256, golden["cw"], golden["cl"], start_bit=int(offs[3]))
+    assert np.array_equal(x[3 * 256: 4 * 256], y3)
