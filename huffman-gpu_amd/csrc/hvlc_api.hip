@@ -483,7 +483,7 @@ int hvlc_merge_shard(hvlc_ctx* c, const uint32_t* d_src_bits, uint64_t nbits, ui
     if (last_word >= dst_capacity_words) return HVLC_ERR_CAPACITY;
     HVLC_HIP(c, hipSetDevice(c->device));
     const uint64_t nd = (((uint32_t)dst_bit_offset & 31u) + nbits + 31u) >> 5;
-    uint64_t grid = (nd + kThreads - 1) / kThreads;
+    uint64_t grid = (nd / 4 + kThreads) / kThreads;          // one thread per four destination words
     const uint64_t cap = (uint64_t)c->cus * 32;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(k_merge_shard, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,

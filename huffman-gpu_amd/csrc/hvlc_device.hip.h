@@ -1279,21 +1279,53 @@ __global__ void __launch_bounds__(kThreads) k_rebase_dev(uint64_t* offs, uint64_
 // stored; the first and last destination words, which the neighbouring shards may also write, are merged with
 // an atomic OR (they must be zero before the first merge).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t merge_word(const uint32_t* __restrict__ src, uint64_t k, uint32_t s, uint64_t nd,
+                                               uint64_t ns, uint64_t nbits)
+{
+    const uint32_t hi = (k >= 1 && k - 1 < ns) ? src[k - 1] : 0u;
+    const uint32_t lo = k < ns ? src[k] : 0u;
+    uint32_t v = s ? __builtin_amdgcn_alignbit(hi, lo, s) : lo;          // ({hi,lo} >> s): hi's low s bits, then lo's top bits
+    if (k == nd - 1) {                                                    // bits past the end of the shard are not ours
+        const uint32_t used = (uint32_t)((s + nbits) & 31u);
+        if (used) v &= ~0u << (32u - used);
+    }
+    return v;
+}
+
 __global__ void __launch_bounds__(kThreads) k_merge_shard(const uint32_t* __restrict__ src, uint64_t nbits,
                                                           uint32_t* __restrict__ dst, uint64_t dst_bit_offset)
 {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const uint32_t s  = (uint32_t)dst_bit_offset & 31u;
     const uint64_t w0 = dst_bit_offset >> 5;
     const uint64_t nd = (s + nbits + 31u) >> 5;                   // destination words touched
     const uint64_t ns = (nbits + 31u) >> 5;                       // source words holding bits (zero padded by the encoder)
-    for (uint64_t k = (uint64_t)blockIdx.x * kThreads + threadIdx.x; k < nd; k += (uint64_t)gridDim.x * kThreads) {
-        const uint32_t hi = (k >= 1 && k - 1 < ns) ? src[k - 1] : 0u;
-        const uint32_t lo = k < ns ? src[k] : 0u;
-        uint32_t v = s ? __builtin_amdgcn_alignbit(hi, lo, s) : lo;      // ({hi,lo} >> s): hi's low s bits, then lo's top bits
-        if (k == nd - 1) {                                                // bits past the end of the shard are not ours
-            const uint32_t used = (uint32_t)((s + nbits) & 31u);
-            if (used) v &= ~0u << (32u - used);
-        }
+    // interior destination words in 16-byte aligned groups of four: relative k in [kg, kg + 4 * ng)
+    uint64_t kg = ((w0 + 1 + 3) & ~3ull) - w0;                    // first group starts behind the (atomic) first word
+    uint64_t ng = 0;
+    if (nd >= 2 && kg + 4 <= nd - 1) {
+        ng = (nd - 1 - kg) / 4;
+        while (ng > 0 && kg + 4 * ng > ns) --ng;                  // every source word of a group must exist (k + 3 < ns)
+    }
+    if (ng == 0) kg = nd;                                         // no vector part: everything goes word by word
+    const uint64_t tid0 = (uint64_t)blockIdx.x * kThreads + threadIdx.x, nthr = (uint64_t)gridDim.x * kThreads;
+    for (uint64_t t = tid0; t < ng; t += nthr) {
+        const uint64_t k = kg + 4 * t;
+        const uint32_t hi = src[k - 1];
+        const u32x4 lo = __builtin_nontemporal_load((const u32x4*)(src + k));      // 4-byte aligned is enough for global loads
+        u32x4 v;
+        v.x = s ? __builtin_amdgcn_alignbit(hi,   lo.x, s) : lo.x;
+        v.y = s ? __builtin_amdgcn_alignbit(lo.x, lo.y, s) : lo.y;
+        v.z = s ? __builtin_amdgcn_alignbit(lo.y, lo.z, s) : lo.z;
+        v.w = s ? __builtin_amdgcn_alignbit(lo.z, lo.w, s) : lo.w;
+        *(u32x4*)(dst + w0 + k) = v;
+    }
+    // the words in front of and behind the vector part (the first and the last one of the shard: atomic)
+    const uint64_t head = kg < nd ? kg : nd, tail0 = kg + 4 * ng;
+    const uint64_t nscalar = head + (tail0 < nd ? nd - tail0 : 0);
+    for (uint64_t t = tid0; t < nscalar; t += nthr) {
+        const uint64_t k = t < head ? t : tail0 + (t - head);
+        const uint32_t v = merge_word(src, k, s, nd, ns, nbits);
         if (k == 0 || k == nd - 1) { if (v) atomicOr(&dst[w0 + k], v); }
         else dst[w0 + k] = v;
     }
