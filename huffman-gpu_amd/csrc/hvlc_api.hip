@@ -57,7 +57,7 @@ constexpr uint64_t kHeaderBytes = kLutBytes + kStatusBytes;
 inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
 // workspace behind the header, for an encoder call of `tiles` tiles (offsets in bytes):
-//   tickets [8 x 128 B] | bits32 [round_up(tiles, 64)] | recs [tiles + 1] | group_desc [groups, padded to 8 + 8]
+//   tickets [8 x 128 B] | bits32 [round_up(tiles, 64)] | recs [tiles + 1] | group_desc [groups, padded for the leaders' 16-granule window]
 // k_exclusive_scan reuses the same area as  tile_bits [tiles] | group_desc [groups]  (8 bytes each).
 struct Layout { uint64_t off_tickets, off_bits32, off_recs, off_groups, bytes, scan_off_groups, scan_bytes; };
 inline Layout layout_for(uint64_t tiles)
@@ -68,7 +68,7 @@ inline Layout layout_for(uint64_t tiles)
     l.off_bits32 = (uint64_t)kTicketClasses * kTicketStride * 4;
     l.off_recs   = l.off_bits32 + round_up(round_up(tiles, kGroupTiles) * 4, 64);
     l.off_groups = l.off_recs + round_up((tiles + 1) * sizeof(TileRec), 64);
-    l.bytes      = l.off_groups + (round_up(groups, 8) + 8) * 8;
+    l.bytes      = l.off_groups + (round_up(groups, kWindow) + kWindow) * 8;
     l.scan_off_groups = round_up(tiles * 8, 64);
     l.scan_bytes = l.scan_off_groups + (groups + 1) * 8;
     if (l.bytes < l.scan_bytes) l.bytes = round_up(l.scan_bytes, 64);

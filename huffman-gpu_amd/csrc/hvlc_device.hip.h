@@ -188,20 +188,21 @@ __device__ __forceinline__ void st_word(uint32_t* p, uint32_t v)
 }
 
 // One polling round of the scout: ONE vector sc1 load instruction fetches the 16-byte records of up to six
-// tiles (lanes 0-23, a dword each) and, for a group leader, 8 group granules (lanes 32-47); the values are
+// tiles (lanes 0-23, a dword each) and, for a group leader, 16 group granules (lanes 32-63); the values are
 // moved to SGPRs (v_readlane) so that everything the scout decides is scalar code.
 // (Polling through the scalar memory path -- s_load ... glc -- was measured too: half the hand-off latency
 // with two pollers (tools/ubench.hip), but with 1535 scouts polling the scalar caches serialise their misses
 // and the kernel ran 15x slower.)
 constexpr int kMaxSlots = 6;       // records the scout can poll per round
+constexpr int kWindow   = 16;      // group granules a leader looks at per round (lanes 32..63 of the poll)
 // rec_off: per lane, the byte offset (from p.recs) of the dword this lane polls: lane 4s+k -> dword k of slot s's record
 template <bool WINDOW>
 __device__ __forceinline__ uint32_t poll_round(const EncodeParams& p, uint32_t rec_off, const void* w, int lane)
 {
     const char* src = (const char*)p.recs + rec_off;
-    if (WINDOW && lane >= 32) src = (const char*)w + (uint32_t)(lane - 32) * 4u;   // lanes 32..47: the 16 dwords of the window
+    if (WINDOW && lane >= 32) src = (const char*)w + (uint32_t)(lane - 32) * 4u;   // lanes 32..63: the 32 dwords of the window
     uint32_t v = 0;
-    if (lane < 4 * kMaxIn || (WINDOW && lane >= 32 && lane < 48))
+    if (lane < 4 * kMaxIn || (WINDOW && lane >= 32))
         v = __hip_atomic_load((const uint32_t*)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return v;
 }
@@ -904,7 +905,7 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
 //
 // Offsets come from a two-level scan over the granules: the LAST tile of every 64-tile group is the
 // group's leader.  Its scout (LeaderDuty) reads the 64 bit counts of the group (one vector load),
-// publishes the group's aggregate, walks the group granules downwards (8 per round) to the nearest
+// publishes the group's aggregate, walks the group granules downwards (16 per round) to the nearest
 // inclusive prefix, publishes the group's inclusive prefix and then the global offset of EVERY tile of the
 // group (one 64-lane store into the records).  So a tile's offset costs its own scout one poll per round,
 // and the chain packed -> leader -> records is three hand-offs whatever the input size.
@@ -964,17 +965,17 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
         }
 
         // (1) this round's requests: the leader's bit counts (vector, asynchronous), then the records of the
-        //     tiles in flight and, for a leader, 8 group granules, in one scalar block
+        //     tiles in flight and, for a leader, 16 group granules, in one vector load
         uint32_t bv = kValid32;
         if (d.active && !d.have_bits && (uint32_t)lane < d.n)
             bv = __hip_atomic_load(&p.bits32[(uint64_t)d.g * kGroupTiles + (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t pv;                     // lanes 0-23: the records of the tiles in flight; lanes 32-47: the leader's window
+        uint32_t pv;                     // lanes 0-23: the records of the tiles in flight; lanes 32-63: the leader's window
         if (d.active && !d.win_done) {
-            const int32_t c0 = d.j & ~7;
+            const int32_t c0 = d.j & ~(kWindow - 1);
             pv = poll_round<true>(p, rec_off, p.group_desc + c0, lane);
             bool stop = false;
 #pragma unroll
-            for (int i = 7; i >= 0; --i) {
+            for (int i = kWindow - 1; i >= 0; --i) {
                 if (!stop && c0 + i <= d.j) {
                     const uint64_t v  = ((uint64_t)lane_value(pv, 33 + 2 * i) << 32) | (uint64_t)lane_value(pv, 32 + 2 * i);
                     const uint32_t st = (uint32_t)(v >> 62);

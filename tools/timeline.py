@@ -23,7 +23,8 @@ def main():
     cw, cl = hvlc.huffman_table(hist); d_tab = enc.table_to_device(cw, cl)
     out = torch.empty(hvlc.out_capacity_words(n // 4, int(cl.max())), dtype=torch.int32, device="cuda")
     offs = torch.empty(hvlc.num_segments(n // 4), dtype=torch.int64, device="cuda")
-    ntiles = n // 12288 + (1 if n % 12288 else 0)
+    TILE = 28672                                     # bytes per tile (kTileWords * 4)
+    ntiles = n // TILE + (1 if n % TILE else 0)
     for it in range(3):
         tl = torch.zeros(ntiles * 8, dtype=torch.int64, device="cuda")
         L.hvlc_debug_set_timeline(C.c_void_p(tl.data_ptr()))
