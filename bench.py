@@ -82,7 +82,7 @@ def main():
     if world > 1:
         dist.all_reduce(hist)                              # table of the WHOLE job's histogram
     hist_np = hist.cpu().numpy().astype(np.uint64)
-    cw, cl = hvlc.huffman_table(hist_np)
+    cw, cl = hvlc.build_table(hist_np)                     # libhvlc's host-side table builder
     max_len = int(cl.max())
     d_table = enc.table_to_device(cw, cl)
     S = hvlc.num_segments(n_words)

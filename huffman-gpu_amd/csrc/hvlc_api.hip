@@ -17,8 +17,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <cmath>
+#include <functional>
 #include <mutex>
 #include <new>
+#include <queue>
+#include <utility>
+#include <vector>
 
 using namespace hvlc;
 
@@ -471,6 +477,68 @@ int hvlc_rebase_offsets_dev(hvlc_ctx* c, uint64_t* d_offsets, uint64_t n,
     hipLaunchKernelGGL(k_rebase_dev, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
                        d_offsets, n, d_shard_totals, rank);
     HVLC_HIP(c, hipGetLastError());
+    return HVLC_OK;
+}
+
+// SURVEY.md section 8(f) #2 -- the table for a byte histogram, on the host (the reference builds its table on the
+// host too: huffTree.h:55-94 + load_data.h:40-47).  Huffman code lengths by the textbook two-smallest merge
+// (ties: the older node first, so the result is deterministic), lengths above max_len repaired by flattening
+// the deepest leaves and lengthening the cheapest symbols until the Kraft sum is <= 1, then CANONICAL codewords
+// (sorted by length, then symbol), right-aligned -- the table format hvlc_encode takes.
+int hvlc_build_table(const uint64_t* hist, uint32_t max_len, uint32_t* codewords, uint32_t* codewordlens)
+{
+    if (!hist || !codewords || !codewordlens || max_len < 8 || max_len > 31) return HVLC_ERR_ARG;
+    uint32_t lens[256] = {0};
+    struct Node { uint64_t w; uint32_t order; int left, right; };
+    std::vector<Node> nodes;
+    typedef std::pair<std::pair<uint64_t, uint32_t>, int> Item;          // ((weight, order), node)
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> pq;
+    for (int s = 0; s < 256; ++s)
+        if (hist[s]) { nodes.push_back({hist[s], (uint32_t)s, -1, -1}); pq.push({{hist[s], (uint32_t)s}, (int)nodes.size() - 1}); }
+    int live = (int)nodes.size();
+    if (live == 1) lens[nodes[0].order] = 1;
+    uint32_t order = 256;
+    while (pq.size() > 1) {
+        const Item a = pq.top(); pq.pop();
+        const Item b = pq.top(); pq.pop();
+        nodes.push_back({a.first.first + b.first.first, order, a.second, b.second});
+        pq.push({{a.first.first + b.first.first, order}, (int)nodes.size() - 1});
+        ++order;
+    }
+    if (live > 1) {                                                       // depth of every leaf
+        std::vector<std::pair<int, uint32_t>> st;
+        st.push_back({pq.top().second, 0u});
+        while (!st.empty()) {
+            const std::pair<int, uint32_t> t = st.back(); st.pop_back();
+            const Node& n = nodes[t.first];
+            if (n.left < 0) lens[n.order] = t.second;
+            else { st.push_back({n.left, t.second + 1}); st.push_back({n.right, t.second + 1}); }
+        }
+    }
+    uint32_t mx = 0;
+    for (int s = 0; s < 256; ++s) if (lens[s] > mx) mx = lens[s];
+    if (mx > max_len) {
+        std::vector<int> ord;
+        for (int s = 0; s < 256; ++s) if (lens[s]) ord.push_back(s);
+        std::sort(ord.begin(), ord.end(), [&](int x, int y) {
+            if (lens[x] != lens[y]) return lens[x] > lens[y];
+            if (hist[x] != hist[y]) return hist[x] < hist[y];
+            return x < y; });
+        for (int s : ord) if (lens[s] > max_len) lens[s] = max_len;
+        long double kraft = 0;
+        for (int s : ord) kraft += ldexpl(1.0L, -(int)lens[s]);
+        size_t i = ord.size() - 1;
+        while (kraft > 1.0L + 1e-18L) {                                   // lengthen the cheapest symbols that can still grow
+            const int s = ord[i];
+            if (lens[s] < max_len) { kraft -= ldexpl(1.0L, -(int)(lens[s] + 1)); lens[s] += 1; }
+            i = i > 0 ? i - 1 : ord.size() - 1;
+        }
+    }
+    std::vector<std::pair<uint32_t, int>> bylen;
+    for (int s = 0; s < 256; ++s) { codewords[s] = 0; codewordlens[s] = lens[s]; if (lens[s]) bylen.push_back({lens[s], s}); }
+    std::sort(bylen.begin(), bylen.end());
+    uint32_t code = 0, prev = 0;
+    for (const auto& e : bylen) { code <<= (e.first - prev); codewords[e.second] = code; ++code; prev = e.first; }
     return HVLC_OK;
 }
 

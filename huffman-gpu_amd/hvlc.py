@@ -31,7 +31,7 @@ EXPORTS = [
     "hvlc_create", "hvlc_destroy", "hvlc_out_capacity_words", "hvlc_num_segments", "hvlc_encode",
     "hvlc_finish", "gpu_vlc_encode", "hvlc_segment_bits", "hvlc_exclusive_scan", "hvlc_rebase_offsets",
     "hvlc_rebase_offsets_dev", "hvlc_profile_begin", "hvlc_profile_collect",
-    "hvlc_gen_symbols", "hvlc_histogram", "hvlc_merge_shard", "hvlc_decode", "hvlc_get_launch_info", "hvlc_last_hip_error",
+    "hvlc_gen_symbols", "hvlc_histogram", "hvlc_build_table", "hvlc_merge_shard", "hvlc_decode", "hvlc_get_launch_info", "hvlc_last_hip_error",
     "hvlc_status_string", "hvlc_version",
 ]
 
@@ -358,6 +358,16 @@ def canonical_codes(lens):
 def huffman_table(counts, max_len=MAX_CODE_LEN):
     lens = huffman_lengths(counts, max_len)
     return canonical_codes(lens), lens
+
+
+def build_table(counts, max_len=MAX_CODE_LEN):
+    """The library's own host-side table builder (C ABI hvlc_build_table): (codewords, lengths)."""
+    h = np.ascontiguousarray(counts, dtype=np.uint64)
+    assert h.shape == (256,)
+    cw = np.zeros(256, dtype=np.uint32); cl = np.zeros(256, dtype=np.uint32)
+    _check(lib().hvlc_build_table(h.ctypes.data_as(C.c_void_p), C.c_uint32(int(max_len)),
+                                  cw.ctypes.data_as(C.c_void_p), cl.ctypes.data_as(C.c_void_p)), "hvlc_build_table")
+    return cw, cl
 
 
 def cdf32_from_counts(weights):

@@ -150,6 +150,13 @@ int hvlc_gen_symbols(hvlc_ctx* ctx, uint8_t* d_out, uint64_t n_bytes, uint64_t s
 int hvlc_histogram(hvlc_ctx* ctx, const uint8_t* d_data, uint64_t n_bytes,
                    uint64_t* d_hist, void* stream);
 
+/* SURVEY.md section 8(f) #2 -- code table for a byte histogram (HOST function, no device needed; hvlc_histogram
+ * produces the histogram on the device).  Replaces the reference's host-side table construction (huffTree.h:55-94,
+ * load_data.h:40-47): Huffman code lengths (symbols with count 0 get length 0 = emit nothing), limited to max_len
+ * (8..31) bits, canonical codewords right-aligned in `length` bits -- the table format hvlc_encode takes.
+ * Any Huffman code has the same total cost as the reference's table; the codewords themselves differ. */
+int hvlc_build_table(const uint64_t* hist, uint32_t max_len, uint32_t* codewords, uint32_t* codewordlens);
+
 /* SURVEY.md section 8(f) #1 -- seam merge / contiguous stream materialisation.  Copies the `nbits` bits of a
  * stream that starts at bit 0 of d_src_bits (a shard's output of hvlc_encode; may be P2P-mapped memory of a peer
  * GPU) to bit position dst_bit_offset of d_dst_bits: what pack2 (pack_kernels.cu:19-52) does for 256-word

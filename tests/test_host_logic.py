@@ -65,3 +65,34 @@ def test_extract_bits_roundtrip():
         s = s + "0" * (-len(s) % 32)
         exp = [int(s[i:i + 32], 2) for i in range(0, len(s), 32)]
         assert [int(v) for v in got] == exp
+
+
+def test_c_abi_table_builder_matches_the_python_one(golden):
+    """hvlc_build_table (host C++ inside libhvlc.so, no GPU needed) builds the same canonical table
+    as hvlc.huffman_table for real, random, skewed and degenerate histograms."""
+    rng = np.random.default_rng(11)
+    hists = [np.bincount(golden["period"], minlength=256), np.zeros(256, dtype=np.uint64)]
+    h = np.zeros(256, dtype=np.uint64); h[200] = 9; hists.append(h)
+    for _ in range(20):
+        h = rng.integers(0, 1000, size=256).astype(np.uint64)
+        h[rng.random(256) < 0.3] = 0
+        hists.append(h)
+    for _ in range(10):
+        hists.append(np.floor(rng.pareto(0.6, size=256) * 10).astype(np.uint64))
+    for h in hists:
+        cw, cl = hvlc.build_table(h)
+        pw, pl = hvlc.huffman_table(h)
+        assert np.array_equal(cl, pl) and np.array_equal(cw, pw)
+        assert _prefix_free(cw, cl) and ((cl > 0) == (np.asarray(h) > 0)).all()
+    # length-limited: a Fibonacci histogram wants 59-bit codes
+    fib = np.zeros(256, dtype=np.uint64); a, b = 1, 1
+    for i in range(60):
+        fib[i] = a; a, b = b, a + b
+    for ml in (31, 16, 12):
+        cw, cl = hvlc.build_table(fib, ml)
+        assert cl.max() <= ml and _prefix_free(cw, cl) and sum(2.0 ** -int(l) for l in cl if l) <= 1.0 + 1e-12
+        assert (cw < (np.uint64(1) << cl.astype(np.uint64))).all()
+    # the reference's table has the same cost on its own test file
+    hist = np.bincount(np.tile(golden["period"], 4), minlength=256).astype(np.uint64)
+    _, cl = hvlc.build_table(hist)
+    assert int((hist * cl).sum()) == int((hist * golden["cl"]).sum())
