@@ -269,7 +269,7 @@ int hvlc_encode(hvlc_ctx* c,
 
     EncodeParams p;
     memset(&p, 0, sizeof(p));
-    if (tiles > 0xfffffff0ull) return HVLC_ERR_ARG;          // 32-bit tile numbers: 64 TiB per call
+    if (tiles > 0x0ffffff0ull) return HVLC_ERR_ARG;          // 28-bit tile numbers (32-bit record offsets): 7 TiB per call
     p.in = (const uint4*)d_in;  p.num_words = num_words;  p.num_tiles = tiles;
     p.num_full_tiles = (uint32_t)(num_words / kTileWords);
     p.num_segs = hvlc_num_segments(num_words);
