@@ -8,15 +8,23 @@
  * against the oracle is done by the tests (tests/test_c_harness_gpu.py), which run this binary and compare
  * its dump with oracle/.
  *
- *   hvlc_bench <input file> <table file: codewords[256] | lens[256], uint32 LE> [--iters N] [--dump PREFIX]
+ *   hvlc_bench <input file> <table file: codewords[256] | lens[256], uint32 LE, or "-"> [--iters N]
+ *              [--dump PREFIX] [--verify] [--stats DIR]
  *
- * Tail bytes beyond a multiple of 4 are dropped, as load_data.h:19 does (num_elements = mem_size / 4).
+ * Table "-": the table is built from the file itself as loadData does (load_data.h:25-58): byte histogram on the
+ * device (hvlc_histogram), Huffman table on the host (hvlc_build_table), entropy line printed in the reference's
+ * format.  --verify decodes the stream on the device (hvlc_decode) and compares it with the input.
+ * --stats DIR appends one point (input MiB, encode GB/s) to a series file in the reference's stats_logger format
+ * (stats_logger.cpp:26-42).  Tail bytes beyond a multiple of 4 are dropped, as load_data.h:19 does
+ * (num_elements = mem_size / 4), but -- unlike the reference, whose grid needs multiples of 4096 words
+ * (load_data.h:21) -- every whole word is encoded.
  */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 #include "../../include/hvlc.h"
 
@@ -41,18 +49,39 @@ static void* read_file(const char* path, size_t* size)
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { fprintf(stderr, "usage: %s <input> <table.bin> [--iters N] [--dump PREFIX]\n", argv[0]); return 1; }
-    int iters = 10;
+    if (argc < 3) { fprintf(stderr, "usage: %s <input> <table.bin|-> [--iters N] [--dump PREFIX] [--verify] [--stats DIR]\n", argv[0]); return 1; }
+    int iters = 10, verify = 0;
     const char* dump = NULL;
+    const char* stats = NULL;
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--dump") && i + 1 < argc) dump = argv[++i];
+        else if (!strcmp(argv[i], "--stats") && i + 1 < argc) stats = argv[++i];
+        else if (!strcmp(argv[i], "--verify")) verify = 1;
     }
+    const int build = !strcmp(argv[2], "-");
     size_t in_bytes = 0, tab_bytes = 0;
     uint32_t* in = (uint32_t*)read_file(argv[1], &in_bytes);
-    uint32_t* tab = (uint32_t*)read_file(argv[2], &tab_bytes);
-    if (!in || !tab || tab_bytes != 2048) { fprintf(stderr, "bad input or table (need 2048-byte table)\n"); return 1; }
+    uint32_t* tab = build ? (uint32_t*)calloc(512, 4) : (uint32_t*)read_file(argv[2], &tab_bytes);
+    if (!in || !tab || (!build && tab_bytes != 2048)) { fprintf(stderr, "bad input or table (need 2048-byte table)\n"); return 1; }
     const uint64_t W = in_bytes / 4;
+    if (build) {                                      /* loadData (load_data.h:25-58): histogram -> table -> entropy */
+        hvlc_ctx* h0 = NULL;
+        uint8_t* d_b; uint64_t* d_h; uint64_t hist[256];
+        CHECK_HIP(hipSetDevice(0));
+        CHECK_HV(hvlc_create(&h0, 0, 0));
+        CHECK_HIP(hipMalloc((void**)&d_b, W ? W * 4 : 4));
+        CHECK_HIP(hipMalloc((void**)&d_h, 256 * 8));
+        CHECK_HIP(hipMemcpy(d_b, in, W * 4, hipMemcpyHostToDevice));
+        CHECK_HV(hvlc_histogram(h0, d_b, W * 4, d_h, NULL));
+        CHECK_HIP(hipMemcpy(hist, d_h, 256 * 8, hipMemcpyDeviceToHost));
+        CHECK_HV(hvlc_build_table(hist, 31, tab, tab + 256));
+        double H = 0.0;
+        for (int s = 0; s < 256; ++s)
+            if (hist[s]) { const double pr = (double)hist[s] / (double)(W * 4); H -= pr * log(pr) / log(2.0); }
+        printf("\n%s, %llu bytes, entropy %f\n\n", argv[1], (unsigned long long)(W * 4), H);      /* load_data.h:56 */
+        hipFree(d_b); hipFree(d_h); hvlc_destroy(h0);
+    }
     uint32_t max_len = 0;
     for (int s = 0; s < 256; ++s) if (tab[256 + s] > max_len) max_len = tab[256 + s];
     const uint64_t cap = hvlc_out_capacity_words(W, max_len);
@@ -101,16 +130,46 @@ int main(int argc, char** argv)
         fwrite(offs, 8, S, f); fclose(f);
         free(out); free(offs);
     }
+    int verified = -1;
+    if (verify) {                                     /* round trip on the device: decode and compare with the input */
+        uint32_t* d_back;
+        CHECK_HIP(hipMalloc((void**)&d_back, W ? W * 4 : 4));
+        CHECK_HV(hvlc_decode(hv, d_out, bits, d_offs, d_tab, d_tab + 256, d_back, W, NULL));
+        uint32_t* back = (uint32_t*)malloc(W ? W * 4 : 4);
+        CHECK_HIP(hipMemcpy(back, d_back, W * 4, hipMemcpyDeviceToHost));
+        verified = memcmp(back, in, W * 4) == 0;
+        free(back); hipFree(d_back);
+        if (!verified) fprintf(stderr, "VERIFY FAILED: decode(encode(input)) != input\n");
+    }
+    if (stats) {                                      /* one point of the series, stats_logger.cpp:26-42 format */
+        char path[1024];
+        snprintf(path, sizeof path, "%s/encoding__0_hvlc.txt", stats);
+        FILE* probe = fopen(path, "rt");
+        FILE* f = fopen(path, "at");
+        if (!f) { perror(path); return 1; }
+        if (!probe)
+            fprintf(f, "SERIES_NAME\nhvlc\nX_AXIS_QUANTITY\ninput size\nY_AXIS_QUANTITY\nencode throughput\nX_AXIS_UNIT\nMiB\n"
+                       "Y_AXIS_UNIT\nGB/s\nX_AXIS_SCALE_TYPE\nlog\nY_AXIS_SCALE_TYPE\nlin\nDESCRIPTION\nlibhvlc %s\n__DATA__\n", hvlc_version());
+        else fclose(probe);
+        fprintf(f, "%f %f\n", (double)W * 4 / 1048576.0, ms > 0 ? (double)W * 4 / ms / 1e6 : 0.0);
+        fclose(f);
+    }
     int grid = 0, bpc = 0, cus = 0;
     hvlc_get_launch_info(hv, &grid, &bpc, &cus);
     /* the reference prints refbytesize the same way: whole words * 4 + remaining bits rounded up (cpuencode.cpp:44-45) */
     const uint64_t outsize = (bits >> 5) * 4 + ((bits & 31) + 7) / 8;
     printf("{\"input_bytes\": %llu, \"total_bits\": %llu, \"outsize\": %llu, \"ms\": %.4f, \"GBps_in\": %.2f, "
-           "\"grid\": %d, \"blocks_per_cu\": %d, \"cus\": %d, \"version\": \"%s\"}\n",
+           "\"grid\": %d, \"blocks_per_cu\": %d, \"cus\": %d, \"verified\": %d, \"tail_bytes_dropped\": %d, \"version\": \"%s\"}\n",
            (unsigned long long)(W * 4), (unsigned long long)bits, (unsigned long long)outsize, ms,
-           ms > 0 ? (double)W * 4 / ms / 1e6 : 0.0, grid, bpc, cus, hvlc_version());
+           ms > 0 ? (double)W * 4 / ms / 1e6 : 0.0, grid, bpc, cus, verified, (int)(in_bytes & 3), hvlc_version());
+    if (dump && build) {                              /* the table that was built, in the table-file format */
+        char path[1024];
+        snprintf(path, sizeof path, "%s.table.bin", dump);
+        FILE* f = fopen(path, "wb"); if (!f) { perror(path); return 1; }
+        fwrite(tab, 4, 512, f); fclose(f);
+    }
     hvlc_destroy(hv);
     hipFree(d_in); hipFree(d_tab); hipFree(d_out); hipFree(d_offs);
     free(in); free(tab);
-    return 0;
+    return verified == 0 ? 4 : 0;
 }
