@@ -527,13 +527,17 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
 __device__ __forceinline__ void store_words(const EncodeParams& p, const uint32_t* sb, uint32_t s,
                                             uint64_t ow, uint32_t nown, int tid)
 {
-    for (uint32_t k = (uint32_t)tid; k < nown; k += kDataThreads) {
-        const uint32_t v = __builtin_amdgcn_alignbit(sb[k], sb[k + 1], s);
-        const uint64_t idx = ow + k;
-        if (HVLC_DBG(p, kDbgNoStore)) { if (v == 0x12345u) p.out[0] = v; continue; }
-        if (idx < p.out_cap) p.out[idx] = v;
-        else atomicOr(p.status, kFlagCapacity);
+    // capacity: decided once per call (all arguments are wave-uniform), not per word
+    if (ow + nown > p.out_cap) {
+        if (tid == 0) atomicOr(p.status, kFlagCapacity);
+        nown = ow < p.out_cap ? (uint32_t)(p.out_cap - ow) : 0u;
     }
+    if (HVLC_DBG(p, kDbgNoStore)) return;
+    uint32_t* const dst = p.out + ow;                           // scalar base, 32-bit per-lane offsets
+    // one word per lane and trip: consecutive lanes read consecutive LDS words (no bank conflicts; four words per
+    // lane and a dwordx4 store were measured: fewer instructions, but 8-way conflicts on the strided LDS reads)
+    for (uint32_t k = (uint32_t)tid; k < nown; k += kDataThreads)
+        dst[k] = __builtin_amdgcn_alignbit(sb[k], sb[k + 1], s);
 }
 
 __device__ __forceinline__ void zero_words(uint32_t* base, uint32_t n_vec4, int tid)
