@@ -762,11 +762,6 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
         uint64_t acc[kRows];
         uint32_t tot[kRows], excl[kRows], rowbase[kRows];
         STAMP(0);
-        if (do_store) {
-            const uint32_t st_tile = uni(sm.tq[c.n_stored % kTq]);
-            TL(p, st_tile, 5, tid == 0);
-            finish_tile(p, sm, st_tile, ss, tid);
-        }
         STAMP(1);
         if (can_pack) {
             uint32_t wavetot = 0;
@@ -799,6 +794,14 @@ __device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& s
             }
             if (lane == 0) sm.wave_tot[wave] = wavetot;
             STAMP(2);
+        }
+        // The stream stores of the oldest tile go BEHIND the encode: vector-memory operations retire in order, and the
+        // encode starts by waiting for the tile's input loads -- stores issued in front of that wait would have to be
+        // acknowledged first (a write round trip exposed per tile); issued here they have until the next tile's wait.
+        if (do_store) {
+            const uint32_t st_tile = uni(sm.tq[c.n_stored % kTq]);
+            TL(p, st_tile, 5, tid == 0);
+            finish_tile(p, sm, st_tile, ss, tid);
         }
         if (!can_pack && !do_store) __builtin_amdgcn_s_sleep(8);   // nothing to do this round: wait for the scout
         // the freshest ticket count, sampled by one thread right before the barrier: a tile drawn while this tile was
