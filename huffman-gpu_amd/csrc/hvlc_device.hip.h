@@ -536,6 +536,8 @@ __device__ __forceinline__ void store_words(const EncodeParams& p, const uint32_
     uint32_t* const dst = p.out + ow;                           // scalar base, 32-bit per-lane offsets
     // one word per lane and trip: consecutive lanes read consecutive LDS words (no bank conflicts; four words per
     // lane and a dwordx4 store were measured: fewer instructions, but 8-way conflicts on the strided LDS reads)
+    // (plain stores: non-temporal ones gained 7 % in the decoupled data-path experiment, tools/ubench_datapath.hip, but
+    // nothing here, where neighbouring tiles share the lines at their seams)
     for (uint32_t k = (uint32_t)tid; k < nown; k += kDataThreads)
         dst[k] = __builtin_amdgcn_alignbit(sb[k], sb[k + 1], s);
 }

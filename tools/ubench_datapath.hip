@@ -47,6 +47,11 @@ __global__ void __launch_bounds__(64 * WAVES) k_datapath(const uint4* in, uint64
             excl[r] = incl - tot[r]; rowbase[r] = wavetot;
             wavetot += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
+        if (STORE == 5) {                      // stores first, then the prefetch (loads younger than stores)
+            const uint32_t nown = (wavetot >> 5) & ~3u;
+            uint32_t* dst = out + t * out_stride_words;
+            for (uint32_t k = lane * 4; k < nown; k += 256) *(uint4*)(dst + k) = make_uint4(tot[0], tot[1], tot[2], tot[3]);
+        }
         if (t + nw < num_tiles4k) {
             const u32x4* src = (const u32x4*)in + (t + nw) * 256 + lane;
             for (int r = 0; r < 4; ++r) { const u32x4 v = __builtin_nontemporal_load(src + r * 64); raw[r] = make_uint4(v.x, v.y, v.z, v.w); }
@@ -62,6 +67,12 @@ __global__ void __launch_bounds__(64 * WAVES) k_datapath(const uint4* in, uint64
             const uint32_t nown = (wavetot >> 5) & ~3u;
             uint32_t* dst = out + t * out_stride_words;
             for (uint32_t k = lane * 4; k < nown; k += 256) *(uint4*)(dst + k) = make_uint4(tot[0], tot[1], tot[2], tot[3]);
+        } else if (STORE == 4) {               // dwordx4 NON-TEMPORAL stores from registers
+            const uint32_t nown = (wavetot >> 5) & ~3u;
+            uint32_t* dst = out + t * out_stride_words;
+            typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+            for (uint32_t k = lane * 4; k < nown; k += 256) { u32x4s v = { tot[0], tot[1], tot[2], tot[3] }; __builtin_nontemporal_store(v, (u32x4s*)(dst + k)); }
+        } else if (STORE == 5) {
         } else if (STORE == 3) {               // dword stores from registers (no LDS traffic)
             const uint32_t nown = wavetot >> 5;
             uint32_t* dst = out + t * out_stride_words;
@@ -122,5 +133,7 @@ int main(int argc, char** argv)
     run<4, true, 0>("load+encode+scan+pack", d_in, bytes, d_lut, d_out, d_total, 6);
     run<4, false, 0>("load+encode+scan", d_in, bytes, d_lut, d_out, d_total, 6);
     run<4, false, 2>("load+encode+scan+dwordx4 reg stores", d_in, bytes, d_lut, d_out, d_total, 6);
+    run<4, false, 4>("load+encode+scan+dwordx4 NT stores", d_in, bytes, d_lut, d_out, d_total, 6);
+    run<4, false, 5>("load+encode+scan+stores BEFORE prefetch", d_in, bytes, d_lut, d_out, d_total, 6);
     return 0;
 }
