@@ -18,7 +18,43 @@ using namespace hvlc;
 
 constexpr int kSlotWords = 1024 + 64;     // a wave's 4 KiB tile at up to 8 bits per symbol
 
-template <int WAVES, bool PACK, int STORE>
+// experiment variants of the symbol loop
+template <int MODE>   // 0: product encode16, 1: no slot hash, 2: eight lookups in flight (inline asm), 3: both
+__device__ __forceinline__ void enc16(const uint4& v, const uint2* lut, uint64_t& acc, uint32_t& tot)
+{
+    if (MODE == 0) { encode16<true>(v, 4, lut, acc, tot); return; }
+    const bool nohash = (MODE & 1) != 0;
+    const uint32_t w[4] = { nohash ? v.x : hash4(v.x), nohash ? v.y : hash4(v.y), nohash ? v.z : hash4(v.z), nohash ? v.w : hash4(v.w) };
+    acc = 0; tot = 0;
+    if (MODE & 2) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t ha = w[2 * half], hb = w[2 * half + 1];
+            const uint32_t o0 = slot_offset<3>(ha), o1 = slot_offset<2>(ha), o2 = slot_offset<1>(ha), o3 = slot_offset<0>(ha);
+            const uint32_t o4 = slot_offset<3>(hb), o5 = slot_offset<2>(hb), o6 = slot_offset<1>(hb), o7 = slot_offset<0>(hb);
+            u32x2 r0, r1, r2, r3, r4, r5, r6, r7;
+            asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
+                         "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                         : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(o4), "v"(o5), "v"(o6), "v"(o7) : "memory");
+            const u32x2 e[8] = { r0, r1, r2, r3, r4, r5, r6, r7 };
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { acc = (acc << e[i].y) | e[i].x; tot += e[i].y; }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t h = w[k];
+            { const uint2 e = lut_at(lut, slot_offset<3>(h)); acc = (acc << e.y) | e.x; tot += e.y; }
+            { const uint2 e = lut_at(lut, slot_offset<2>(h)); acc = (acc << e.y) | e.x; tot += e.y; }
+            { const uint2 e = lut_at(lut, slot_offset<1>(h)); acc = (acc << e.y) | e.x; tot += e.y; }
+            { const uint2 e = lut_at(lut, slot_offset<0>(h)); acc = (acc << e.y) | e.x; tot += e.y; }
+        }
+    }
+}
+
+template <int WAVES, bool PACK, int STORE, int MODE = 0>
 __global__ void __launch_bounds__(64 * WAVES) k_datapath(const uint4* in, uint64_t num_tiles4k, const uint2* lut_g, uint32_t* out,
                                                          uint32_t out_stride_words, unsigned long long* total)
 {
@@ -26,7 +62,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_datapath(const uint4* in, uint64
     uint2* lut = (uint2*)raw_smem;                                       // LDS address 0, as lut_at() needs
     uint32_t* slots = (uint32_t*)(raw_smem + 2048);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < 256) lut[lut_slot((uint32_t)tid)] = lut_g[tid];
+    if (tid < 256) lut[(MODE & 1) ? (uint32_t)tid : lut_slot((uint32_t)tid)] = lut_g[tid];
     uint32_t* slot = slots + wave * kSlotWords;
     for (int i = lane; i < kSlotWords; i += 64) slot[i] = 0;
     __syncthreads();
@@ -41,7 +77,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_datapath(const uint4* in, uint64
     unsigned long long bits_sum = 0;
     for (; t < num_tiles4k; t += nw) {
         uint64_t acc[4]; uint32_t tot[4], excl[4], rowbase[4], wavetot = 0;
-        for (int r = 0; r < 4; ++r) encode16<true>(raw[r], 4, lut, acc[r], tot[r]);
+        for (int r = 0; r < 4; ++r) enc16<MODE>(raw[r], lut, acc[r], tot[r]);
         for (int r = 0; r < 4; ++r) {
             const uint32_t incl = wave_incl_scan(tot[r]);
             excl[r] = incl - tot[r]; rowbase[r] = wavetot;
@@ -89,7 +125,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_datapath(const uint4* in, uint64
     if (lane == 0 && bits_sum) atomicAdd(total, bits_sum);
 }
 
-template <int WAVES, bool PACK, int STORE>
+template <int WAVES, bool PACK, int STORE, int MODE = 0>
 static void run(const char* name, const uint4* d_in, uint64_t bytes, const uint2* d_lut, uint32_t* d_out, unsigned long long* d_total,
                 int blocks_per_cu)
 {
@@ -101,7 +137,7 @@ static void run(const char* name, const uint4* d_in, uint64_t bytes, const uint2
     for (int it = 0; it < 5; ++it) {
         CK(hipMemset(d_total, 0, 8));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_datapath<WAVES, PACK, STORE>), dim3(grid), dim3(64 * WAVES), lds, 0, d_in, tiles, d_lut, d_out, 640u, d_total);
+        hipLaunchKernelGGL((k_datapath<WAVES, PACK, STORE, MODE>), dim3(grid), dim3(64 * WAVES), lds, 0, d_in, tiles, d_lut, d_out, 640u, d_total);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
     }
@@ -134,6 +170,11 @@ int main(int argc, char** argv)
     run<4, false, 0>("load+encode+scan", d_in, bytes, d_lut, d_out, d_total, 6);
     run<4, false, 2>("load+encode+scan+dwordx4 reg stores", d_in, bytes, d_lut, d_out, d_total, 6);
     run<4, false, 4>("load+encode+scan+dwordx4 NT stores", d_in, bytes, d_lut, d_out, d_total, 6);
+    run<4, false, 0, 1>("load+encode+scan  NO HASH", d_in, bytes, d_lut, d_out, d_total, 6);
+    run<4, false, 0, 2>("load+encode+scan  8 LOOKUPS IN FLIGHT", d_in, bytes, d_lut, d_out, d_total, 6);
+    run<4, true, 1, 1>("full path  NO HASH", d_in, bytes, d_lut, d_out, d_total, 6);
+    run<4, true, 1, 2>("full path  8 LOOKUPS IN FLIGHT", d_in, bytes, d_lut, d_out, d_total, 6);
+    run<4, true, 1, 3>("full path  BOTH", d_in, bytes, d_lut, d_out, d_total, 6);
     run<4, false, 5>("load+encode+scan+stores BEFORE prefetch", d_in, bytes, d_lut, d_out, d_total, 6);
     return 0;
 }
