@@ -23,6 +23,14 @@ __global__ void __launch_bounds__(256) k_rw(const u32x4* in, uint64_t tiles, uin
         if (MODE == 1 || MODE == 4) { for (uint32_t k = lane; k < wpt; k += 64) dst[k] = v; }
         if (MODE == 2) { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) *(u32x4*)(dst + k) = (u32x4){v, v, v, v}; }
         if (MODE == 3) { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) __builtin_nontemporal_store((u32x4){v, v, v, v}, (u32x4*)(dst + k)); }
+        if (MODE >= 5) {                       // bursts: write BURST tiles' worth of output at once, every BURST-th tile
+            const uint32_t burst = MODE == 5 ? 8u : 32u;
+            const uint64_t it = (t - w0) / nw;
+            if ((it % burst) == burst - 1) {
+                uint32_t* d2 = out + ((it / burst) * nw + w0) * (uint64_t)(wpt * burst);   // a region of its own per wave and burst
+                for (uint32_t k = lane * 4; k + 3 < wpt * burst; k += 256) *(u32x4*)(d2 + k) = (u32x4){v, v, v, v};
+            }
+        }
     }
     if (acc == 0x12345678u) *sink = acc;
 }
@@ -53,6 +61,8 @@ int main()
         run<4>("+ dword stores (contiguous stream)", d_in, bytes, d_out, d_sink, bpc);
         run<2>("+ dwordx4 stores", d_in, bytes, d_out, d_sink, bpc);
         run<3>("+ dwordx4 nt stores", d_in, bytes, d_out, d_sink, bpc);
+        run<5>("+ dwordx4 stores in 9 KiB bursts", d_in, bytes, d_out, d_sink, bpc);
+        run<6>("+ dwordx4 stores in 36 KiB bursts", d_in, bytes, d_out, d_sink, bpc);
     }
     return 0;
 }
