@@ -432,14 +432,14 @@ struct alignas(16) Smem {
     uint32_t  n_tix_snap, n_final_snap;     // data waves: per-iteration snapshots (uniform decisions)
     uint32_t  tix_snap;                     // ... and the ticket count sampled before barrier 1
     uint32_t  n_res_snap;                   // data waves: per-iteration snapshot of n_resolved (uniform decisions)
-    uint32_t  abort_snap;                   // ... and of abort_flag: all four data waves must leave in the same iteration
+    uint32_t  abort_snap;                   // ... and of abort_flag: all data waves must leave in the same iteration
     uint32_t  bar;                          // arrival counter of the data waves' LDS barrier
     uint32_t  abort_flag;
 };
 
-// Barrier among the 4 DATA waves only, through an LDS counter: the scout wave never takes part, so a
+// Barrier among the DATA waves only, through an LDS counter: the scout wave never takes part, so a
 // granule round trip it is waiting for can never stall the data path (s_barrier would include it).
-// LDS operations of one wave complete in order, so a wave that sees all 4 arrivals also sees
+// LDS operations of one wave complete in order, so a wave that sees all arrivals also sees
 // everything the others wrote to LDS before arriving.
 struct DataBarrier {
     uint32_t target = 0;
@@ -679,11 +679,11 @@ __device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, Da
 
 // Workgroup-uniform control state of the data waves' pipeline.
 // Tiles are handed out DYNAMICALLY: every tile a workgroup works on is drawn by its scout from one of
-// kTicketClasses atomic counters (draw k of class c is tile 8k + (c + k) % 8, so the eight classes interleave
-// and the group-leader role rotates over them).  A workgroup draws a tile only when it is about to work on it,
+// kTicketClasses atomic counters (draw k of class c is tile 64k + (c + k) % 64, so the classes interleave, the
+// group-leader role rotates over them and a workgroup never holds two tiles of one group).  A workgroup draws a tile only when it is about to work on it,
 // so (1) no tile ever waits for a workgroup that is not running: forward progress does not depend on the grid
 // being co-resident, and (2) a slow workgroup just draws fewer tiles instead of setting everybody's pace.
-// Tile numbers fit 32 bits (2^32 tiles = 48 TiB of input).
+// Tile numbers are limited to 28 bits by the host (32-bit record offsets): 7 TiB of input per call.
 struct RingCtl {
     uint32_t n_packed = 0, n_stored = 0, n_res = 0;   // tiles packed / stored / resolved (workgroup-local numbering)
     uint32_t n_loaded = 0;                            // tiles whose input loads have been issued (n_packed or n_packed + 1)

@@ -47,7 +47,7 @@ typedef enum hvlc_status {
     HVLC_ERR_NOMEM     = -3,
     HVLC_ERR_TABLE     = -4,   /* a length > 31 or a codeword >= 2^len (precondition of cpuencode.cpp:35) */
     HVLC_ERR_CAPACITY  = -5,   /* stream would not fit out_capacity_words; nothing past it was written */
-    HVLC_ERR_TIMEOUT   = -6,   /* an inter-workgroup wait gave up (workgroups not co-resident); output invalid */
+    HVLC_ERR_TIMEOUT   = -6,   /* an inter-workgroup wait gave up (bounded wait, safety net); output invalid */
     HVLC_ERR_NO_DEVICE = -7
 } hvlc_status;
 
