@@ -515,3 +515,31 @@ def test_round_trip_at_full_size(name, golden):
     assert torch.equal(y.view(torch.uint8), d_in.view(torch.uint8))
     del y, o, offs, d_in
     e.close()
+
+
+@pytest.mark.gpu
+def test_two_contexts_on_two_streams_concurrently(golden):
+    """Two contexts encode different inputs on two HIP streams at the same time.  Each kernel is sized for the whole
+    device, so neither grid is co-resident while both run: tiles are drawn by running workgroups only, both finish,
+    both streams are exact (with co-residency as a requirement this would have been a deadlock)."""
+    ea, eb = hvlc.Encoder(0, 1 << 24), hvlc.Encoder(0, 1 << 24)
+    xa = np.tile(golden["period"], 200).view(np.uint32)                         # 50 MiB
+    xb = np.tile(golden["period"][::-1].copy(), 160).view(np.uint32)[: 160 * 65536 - 777]
+    d_tab = ea.table_to_device(golden["cw"], golden["cl"])
+    da, db = _dev(xa), _dev(xb)
+    oa = torch.empty(hvlc.out_capacity_words(xa.size, 21), dtype=torch.int32, device="cuda")
+    ob = torch.empty(hvlc.out_capacity_words(xb.size, 21), dtype=torch.int32, device="cuda")
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(4):                                                          # launches interleave on the device
+        ea.encode_ptr(da.data_ptr(), xa.size, d_tab.data_ptr(), d_tab.data_ptr() + 1024, oa.data_ptr(), oa.numel(), stream=sa.cuda_stream)
+        eb.encode_ptr(db.data_ptr(), xb.size, d_tab.data_ptr(), d_tab.data_ptr() + 1024, ob.data_ptr(), ob.numel(), stream=sb.cuda_stream)
+    bits_a, rc_a = ea.finish(stream=sa.cuda_stream)
+    bits_b, rc_b = eb.finish(stream=sb.cuda_stream)
+    torch.cuda.synchronize()
+    ra, rba = O.encode(xa, golden["cw"], golden["cl"])
+    rb, rbb = O.encode(xb, golden["cw"], golden["cl"])
+    assert rc_a == 0 and rc_b == 0 and bits_a == rba and bits_b == rbb
+    assert np.array_equal(oa[: rba // 32 + 1].cpu().numpy().view(np.uint32), ra)
+    assert np.array_equal(ob[: rbb // 32 + 1].cpu().numpy().view(np.uint32), rb)
+    ea.close(); eb.close()
