@@ -543,3 +543,36 @@ def test_two_contexts_on_two_streams_concurrently(golden):
     assert np.array_equal(oa[: rba // 32 + 1].cpu().numpy().view(np.uint32), ra)
     assert np.array_equal(ob[: rbb // 32 + 1].cpu().numpy().view(np.uint32), rb)
     ea.close(); eb.close()
+
+
+@pytest.mark.gpu
+def test_encode_is_graph_capturable(golden):
+    """hvlc_encode issues two kernel launches and nothing else (no allocation, no synchronisation once the context is
+    sized), so it can be captured into a HIP graph and replayed on new data."""
+    e = hvlc.Encoder(0, 1 << 22)
+    x1 = np.tile(golden["period"], 16).view(np.uint32)
+    x2 = np.tile(golden["period"][::-1].copy(), 16).view(np.uint32)
+    d_tab = e.table_to_device(golden["cw"], golden["cl"])
+    d_in = _dev(x1)
+    out = torch.empty(hvlc.out_capacity_words(x1.size, 21), dtype=torch.int32, device="cuda")
+    offs = torch.empty(hvlc.num_segments(x1.size), dtype=torch.int64, device="cuda")
+    total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        call = lambda: e.encode_ptr(d_in.data_ptr(), x1.size, d_tab.data_ptr(), d_tab.data_ptr() + 1024,
+                                    out.data_ptr(), out.numel(), offs.data_ptr(), total.data_ptr())
+        call()                                                   # warm-up outside the capture
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            call()
+    for x in (x1, x2, x1):
+        d_in.copy_(_dev(x))
+        g.replay()
+        torch.cuda.synchronize()
+        ref, rbits = O.encode(x, golden["cw"], golden["cl"])
+        _, roffs, _ = O.segment_offsets(x, golden["cl"])
+        assert int(total.item()) == rbits
+        assert np.array_equal(out[: rbits // 32 + 1].cpu().numpy().view(np.uint32), ref)
+        assert np.array_equal(offs.cpu().numpy().view(np.uint64), roffs)
+    e.close()
