@@ -1455,18 +1455,23 @@ __global__ void __launch_bounds__(kThreads) k_gen_symbols(uint32_t* out, uint64_
     }
 }
 
+// Byte histogram, one HBM pass.  Skewed data makes most lanes of a wave hit the same few bins, and LDS atomics on
+// one address serialise: every wave keeps kHistCopies private copies of the histogram (lane % kHistCopies picks
+// one), staggered by one word so that the same bin of different copies falls into different LDS banks.
+constexpr int kHistCopies = 8;
 __global__ void __launch_bounds__(kThreads) k_histogram(const uint8_t* data, uint64_t n_bytes, unsigned long long* hist)
 {
-    __shared__ uint32_t h[4][256];          // one private histogram per wave: 4x fewer LDS atomic collisions
-    for (int i = threadIdx.x; i < 1024; i += kThreads) (&h[0][0])[i] = 0u;
+    __shared__ uint32_t h[4][kHistCopies][257];
+    for (int i = threadIdx.x; i < 4 * kHistCopies * 257; i += kThreads) (&h[0][0][0])[i] = 0u;
     __syncthreads();
-    uint32_t* mine = h[threadIdx.x >> 6];
+    uint32_t* mine = h[threadIdx.x >> 6][threadIdx.x & (kHistCopies - 1)];
     const uint64_t nvec = n_bytes / 16;
-    const uint4* v = (const uint4*)data;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* v = (const u32x4*)data;
     uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * kThreads;
     for (; i < nvec; i += stride) {      // host sizes the grid so a 32-bit bin cannot overflow
-        const uint4 x = v[i];
+        const u32x4 x = __builtin_nontemporal_load(v + i);
         const uint32_t w[4] = { x.x, x.y, x.z, x.w };
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1477,7 +1482,11 @@ __global__ void __launch_bounds__(kThreads) k_histogram(const uint8_t* data, uin
     if (blockIdx.x == 0)
         for (uint64_t j = nvec * 16 + threadIdx.x; j < n_bytes; j += kThreads) atomicAdd(&mine[data[j]], 1u);
     __syncthreads();
-    const uint32_t s = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+    uint32_t s = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2)
+#pragma unroll
+        for (int c2 = 0; c2 < kHistCopies; ++c2) s += h[w2][c2][threadIdx.x];
     if (s) atomicAdd(&hist[threadIdx.x], (unsigned long long)s);
 }
 
