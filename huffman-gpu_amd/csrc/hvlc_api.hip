@@ -569,7 +569,7 @@ int hvlc_decode(hvlc_ctx* c, const uint32_t* d_bits, uint64_t total_bits, const 
     HVLC_HIP(c, hipSetDevice(c->device));
     const uint64_t segs = hvlc_num_segments(num_words);
     uint64_t grid = (segs + kThreads - 1) / kThreads;
-    const uint64_t cap = (uint64_t)c->cus * 8;
+    const uint64_t cap = (uint64_t)c->cus * 4;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(k_decode, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
                        d_bits, total_bits, d_offsets, segs, d_codewords, d_codewordlens, d_out_words, num_words);

@@ -1356,7 +1356,8 @@ __global__ void __launch_bounds__(kThreads) k_merge_shard(const uint32_t* __rest
 // lookup of the next kDecBits stream bits; longer ones by a linear search over the (few) long codes.
 // Precondition: a prefix-free table; symbols with length 0 cannot be decoded.
 // ---------------------------------------------------------------------------------------------
-constexpr int kDecBits = 12;
+constexpr int kDecBits  = 12;
+constexpr int kDecChunk = 32;                  // words a thread decodes between two coalesced flushes of its wave
 __global__ void __launch_bounds__(kThreads) k_decode(const uint32_t* __restrict__ bits, uint64_t total_bits,
                                                      const uint64_t* __restrict__ offsets, uint64_t num_segs,
                                                      const uint32_t* __restrict__ cw, const uint32_t* __restrict__ cl,
@@ -1366,6 +1367,7 @@ __global__ void __launch_bounds__(kThreads) k_decode(const uint32_t* __restrict_
     __shared__ uint32_t lcode[256];                  // long codes, left-aligned in 32 bits
     __shared__ uint8_t  llen[256], lsym[256];
     __shared__ uint32_t nlong;
+    __shared__ uint32_t stage[4][64][kDecChunk + 1]; // per wave: a chunk of every lane's output (+1: bank stagger)
     for (int i = threadIdx.x; i < (1 << kDecBits); i += kThreads) fast[i] = 0;
     if (threadIdx.x == 0) nlong = 0;
     __syncthreads();
@@ -1380,33 +1382,54 @@ __global__ void __launch_bounds__(kThreads) k_decode(const uint32_t* __restrict_
         }
     }
     __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t total_words = (total_bits >> 5) + 1;
-    for (uint64_t seg = (uint64_t)blockIdx.x * kThreads + threadIdx.x; seg < num_segs; seg += (uint64_t)gridDim.x * kThreads) {
-        uint64_t pos = offsets[seg];                 // next bit to read
-        const uint64_t w_first = seg * kSegWords;
-        const uint64_t w_end = w_first + kSegWords < num_words ? w_first + kSegWords : num_words;
-        for (uint64_t w = w_first; w < w_end; ++w) {
-            uint32_t word = 0;
-#pragma unroll 1
-            for (int b = 0; b < 4; ++b) {
-                // the next 32 stream bits, left-aligned
-                const uint64_t wi = pos >> 5; const uint32_t sh = (uint32_t)pos & 31u;
-                const uint32_t hi = wi < total_words ? bits[wi] : 0u;
-                const uint32_t lo = wi + 1 < total_words ? bits[wi + 1] : 0u;
-                const uint32_t win = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
-                uint32_t e = fast[win >> (32 - kDecBits)];
-                uint32_t sym = e >> 8, len = e & 255u;
-                if (len == 0u) {                     // a long code (or an invalid stream: then symbol 0, one bit)
-                    len = 1u; sym = 0u;
-                    for (uint32_t k = 0; k < nlong; ++k) {
-                        const uint32_t L = llen[k];
-                        if (((win ^ lcode[k]) >> (32u - L)) == 0u) { len = L; sym = lsym[k]; break; }
+    // a wave owns 64 consecutive segments; all its lanes run the same number of chunks (a wave-uniform loop)
+    for (uint64_t seg0 = ((uint64_t)blockIdx.x * 4 + wave) * 64; seg0 < num_segs; seg0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t seg = seg0 + (uint64_t)lane;
+        const bool live = seg < num_segs;
+        // 64-bit left-aligned bit buffer, refilled 32 bits at a time
+        uint64_t buf = 0; uint32_t avail = 0; uint64_t next = 0;
+        if (live) {
+            const uint64_t pos = offsets[seg];
+            const uint64_t wi = pos >> 5; const uint32_t skip = (uint32_t)pos & 31u;
+            const uint32_t w0 = wi < total_words ? bits[wi] : 0u, w1 = wi + 1 < total_words ? bits[wi + 1] : 0u;
+            buf = (((uint64_t)w0 << 32) | (uint64_t)w1) << skip;
+            avail = 64u - skip; next = wi + 2;
+        }
+        for (int chunk = 0; chunk < kSegWords / kDecChunk; ++chunk) {
+            if (live) {
+                for (int k = 0; k < kDecChunk; ++k) {
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (avail <= 32u) {
+                            const uint32_t w = next < total_words ? bits[next] : 0u;
+                            buf |= (uint64_t)w << (32u - avail);
+                            avail += 32u; ++next;
+                        }
+                        const uint32_t win = (uint32_t)(buf >> 32);
+                        const uint32_t e = fast[win >> (32 - kDecBits)];
+                        uint32_t sym = e >> 8, len = e & 255u;
+                        if (len == 0u) {             // a long code (or an invalid stream: then symbol 0, one bit)
+                            len = 1u; sym = 0u;
+                            for (uint32_t q = 0; q < nlong; ++q) {
+                                const uint32_t L = llen[q];
+                                if (((win ^ lcode[q]) >> (32u - L)) == 0u) { len = L; sym = lsym[q]; break; }
+                            }
+                        }
+                        buf <<= len; avail -= len;
+                        word = (word << 8) | sym;    // most significant byte first (cpuencode.cpp:28)
                     }
+                    stage[wave][lane][k] = word;
                 }
-                pos += len;
-                word = (word << 8) | sym;            // most significant byte first (cpuencode.cpp:28)
             }
-            out[w] = word;
+            // coalesced flush: one store instruction writes the chunks of two lanes (2 x 128 contiguous bytes)
+            for (int pr = 0; pr < 32; ++pr) {
+                const int j = 2 * pr + (lane >> 5), k = lane & 31;
+                const uint64_t w = (seg0 + (uint64_t)j) * kSegWords + (uint64_t)chunk * kDecChunk + (uint64_t)k;
+                if (w < num_words) out[w] = stage[wave][j][k];   // (lanes of one wave: LDS operations complete in order)
+            }
         }
     }
 }
