@@ -23,6 +23,7 @@
 #include <mutex>
 #include <new>
 #include <queue>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -37,6 +38,10 @@ struct hvlc_ctx {
     uint8_t*  ws            = nullptr;   // [lut 2 KiB][status/result 64 B][granules...]
     uint64_t  granule_bytes = 0;         // capacity of the granule region
     uint64_t  timeout_ticks = 200000000ull;   // 2 s of the 100 MHz real-time counter
+    int       scan_blocks_per_cu = 0;        // k_exclusive_scan occupancy on this device (picked on first use)
+    // test hooks (hvlc_test_hook; never set in production)
+    uint32_t  hook_stall_tile = ~0u;
+    int       hook_force_grid = 0;
     // pinned host mirror for hvlc_finish
     uint32_t* h_status      = nullptr;   // [0] flags, [2..3] total bits
     // optional event pairs around k_encode (hvlc_profile_begin / _collect)
@@ -61,6 +66,18 @@ constexpr uint64_t kHeaderBytes = kLutBytes + kStatusBytes;
     } while (0)
 
 inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
+
+// Kernel launch that reports THIS launch's status: hipLaunchKernel returns it directly, so a stale error
+// left behind by the caller's own HIP calls is neither consumed nor mistaken for ours.
+template <typename... KArgs, typename... Args>
+hipError_t launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args)
+{
+    std::tuple<KArgs...> held(static_cast<KArgs>(args)...);
+    void* ptrs[sizeof...(KArgs) ? sizeof...(KArgs) : 1];
+    size_t i = 0;
+    std::apply([&](auto&... a) { ((ptrs[i++] = (void*)&a), ...); }, held);
+    return hipLaunchKernel((const void*)kernel, grid, block, ptrs, lds, s);
+}
 
 // workspace behind the header, for an encoder call of `tiles` tiles (offsets in bytes):
 //   tickets [8 x 128 B] | bits32 [round_up(tiles, 64)] | recs [tiles + 1] | group_desc [groups, padded for the leaders' 16-granule window]
@@ -160,7 +177,6 @@ int pick_blocks_per_cu(hvlc_ctx* c, K kernel, int block_threads, size_t dyn_lds,
 }
 
 #ifdef HVLC_EXPERIMENT
-uint64_t* g_dbg_buf = nullptr;     // tools/ only: phase stamps
 uint64_t* g_dbg_tl = nullptr;      // tools/ only: per-tile timeline
 #endif
 std::mutex g_default_mu;
@@ -260,28 +276,32 @@ int hvlc_encode(hvlc_ctx* c,
         ((uintptr_t)d_total_bits & 7u))
         return HVLC_ERR_ARG;
     if (out_capacity_words < 1) return HVLC_ERR_ARG;
+    // every argument and limit is checked before anything is allocated or launched
+    const uint64_t tiles = (num_words + kTileWords - 1) / kTileWords;
+    if (tiles > 0x0ffffff0ull) return HVLC_ERR_ARG;          // 28-bit tile numbers (32-bit record offsets): 7 TiB per call
+    uint64_t grid = (uint64_t)c->cus * (uint64_t)c->blocks_per_cu;
+    if (c->hook_force_grid > 0) grid = (uint64_t)c->hook_force_grid;
+    if (grid > tiles) grid = tiles;
+    // every ticket class (block index % kTicketClasses) needs a running workgroup to draw its tiles, and a workgroup
+    // must never hold two tiles of one 64-tile group: devices (or partitions) with fewer than 64 resident
+    // workgroups cannot encode more than one tile per workgroup
+    if (grid < tiles && grid < (uint64_t)kTicketClasses) return HVLC_ERR_ARG;
     HVLC_HIP(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-
-    const uint64_t tiles = (num_words + kTileWords - 1) / kTileWords;
     int rc = ensure_workspace(c, tiles);
     if (rc != HVLC_OK) return rc;
 
     EncodeParams p;
     memset(&p, 0, sizeof(p));
-    if (tiles > 0x0ffffff0ull) return HVLC_ERR_ARG;          // 28-bit tile numbers (32-bit record offsets): 7 TiB per call
     p.in = (const uint4*)d_in;  p.num_words = num_words;  p.num_tiles = tiles;
     p.num_full_tiles = (uint32_t)(num_words / kTileWords);
     p.num_segs = hvlc_num_segments(num_words);
     p.lut = ws_lut(c);  p.out = d_out_bits;  p.out_cap = out_capacity_words;
     p.offsets = d_out_offsets;  p.total_bits = d_total_bits;
     fill_granule_ptrs(c, tiles, p, false);
-    // TEST HOOK (tests/test_encode_gpu.py::test_timeout_is_reported_not_a_hang): the named tile never publishes its
-    // bit count, so every later tile waits for ever -- the bounded waits must turn that into HVLC_ERR_TIMEOUT
-    p.stall_tile = (uint32_t)env_int("HVLC_TEST_STALL_TILE", -1);
+    p.stall_tile = c->hook_stall_tile;                        // ~0 unless a test set it (hvlc_test_hook)
 #ifdef HVLC_EXPERIMENT
     p.dbg = (uint32_t)env_int("HVLC_DBG", 0);
-    p.dbg_buf = g_dbg_buf;
     p.dbg_tl = g_dbg_tl;
 #endif
 
@@ -290,32 +310,31 @@ int hvlc_encode(hvlc_ctx* c,
     int pgrid = (int)((vecs + kThreads - 1) / kThreads);
     if (pgrid < 1) pgrid = 1;
     if (pgrid > 2048) pgrid = 2048;
-    hipLaunchKernelGGL(k_prepare, dim3(pgrid), dim3(kThreads), 0, s,
+    HVLC_HIP(c, launch(k_prepare, dim3(pgrid), dim3(kThreads), 0, s,
                        d_codewords, d_codewordlens, ws_lut(c), ws_status(c), ws_result(c),
                        (uint4*)ws_gran(c), vecs, l.off_recs / 16, d_out_bits, out_capacity_words, d_total_bits,
-                       tiles == 0 ? 1 : 0);
-    HVLC_HIP(c, hipGetLastError());
+                       tiles == 0 ? 1 : 0));
     if (tiles == 0) { c->last_grid = 0; return HVLC_OK; }
 
-    uint64_t grid = (uint64_t)c->cus * (uint64_t)c->blocks_per_cu;
-    // TEST HOOK (tests/test_encode_gpu.py::test_oversubscribed_grid_still_encodes): tiles are drawn by running
-    // workgroups only, so even a grid that is not co-resident must finish with the exact stream
-    const int forced_grid = env_int("HVLC_TEST_FORCE_GRID", 0);
-    if (forced_grid > 0) grid = (uint64_t)forced_grid;
-    if (grid > tiles) grid = tiles;
-    // every ticket class (block index % kTicketClasses) needs a workgroup to draw its tiles
-    if (grid < tiles && grid < (uint64_t)kTicketClasses) return HVLC_ERR_ARG;
     c->last_grid = (int)grid;
     const bool prof = c->ev && c->ev_used < c->ev_cap;
     if (prof) HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used], s));
-    hipLaunchKernelGGL(k_encode, dim3((unsigned)grid), dim3(kEncThreads), sizeof(Smem), s, p);
-    HVLC_HIP(c, hipGetLastError());
+    HVLC_HIP(c, launch(k_encode, dim3((unsigned)grid), dim3(kEncThreads), sizeof(Smem), s, p));
     if (prof) { HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used + 1], s)); c->ev_used++; }
     return HVLC_OK;
 }
 
+int hvlc_test_hook(hvlc_ctx* c, int which, int64_t value)
+{
+    if (!c) return HVLC_ERR_ARG;
+    switch (which) {
+        case HVLC_HOOK_STALL_TILE: c->hook_stall_tile = value < 0 ? ~0u : (uint32_t)value; return HVLC_OK;
+        case HVLC_HOOK_FORCE_GRID: c->hook_force_grid = value > 0 ? (int)value : 0; return HVLC_OK;
+        default: return HVLC_ERR_ARG;
+    }
+}
+
 #ifdef HVLC_EXPERIMENT
-int hvlc_debug_set_buffer(void* d_buf) { g_dbg_buf = (uint64_t*)d_buf; return 0; }
 int hvlc_debug_set_timeline(void* d_buf) { g_dbg_tl = (uint64_t*)d_buf; return 0; }
 #endif
 
@@ -419,9 +438,8 @@ int hvlc_segment_bits(hvlc_ctx* c, const uint32_t* d_in, uint64_t num_words,
     uint64_t grid = (segs + 3) / 4;
     const uint64_t cap = (uint64_t)c->cus * 16;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(k_segment_bits, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
-                       d_in, num_words, d_codewordlens, d_counts, segs);
-    HVLC_HIP(c, hipGetLastError());
+    HVLC_HIP(c, launch(k_segment_bits, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
+                       d_in, num_words, d_codewordlens, d_counts, segs));
     return HVLC_OK;
 }
 
@@ -443,14 +461,17 @@ int hvlc_exclusive_scan(hvlc_ctx* c, const uint32_t* d_counts, uint64_t n,
     p.num_tiles = tiles;
     fill_granule_ptrs(c, tiles, p, true);
     const Layout l = layout_for(tiles);
-    HVLC_HIP(c, hipMemsetAsync(ws_gran(c), 0, l.scan_bytes, s));
-    HVLC_HIP(c, hipMemsetAsync(ws_status(c), 0, 16, s));
-    static int scan_bpc = 0;
-    if (!scan_bpc) scan_bpc = pick_blocks_per_cu(c, k_exclusive_scan, kThreads, 0, 4);
+    // granules zeroed and the status word reset by a kernel: the status word is only ever touched with atomic
+    // RMWs (k_prepare's comment), never by a memset
+    const uint64_t vecs = round_up(l.scan_bytes, 16) / 16;
+    int pgrid = (int)((vecs + kThreads - 1) / kThreads);
+    if (pgrid > 2048) pgrid = 2048;
+    HVLC_HIP(c, launch(k_scan_reset, dim3(pgrid), dim3(kThreads), 0, s, (uint4*)ws_gran(c), vecs, ws_status(c), ws_result(c)));
+    if (!c->scan_blocks_per_cu) c->scan_blocks_per_cu = pick_blocks_per_cu(c, k_exclusive_scan, kThreads, 0, 4);
+    const int scan_bpc = c->scan_blocks_per_cu;
     uint64_t grid = (uint64_t)c->cus * (uint64_t)scan_bpc;
     if (grid > tiles) grid = tiles;
-    hipLaunchKernelGGL(k_exclusive_scan, dim3((unsigned)grid), dim3(kThreads), 0, s, d_counts, n, d_offsets, d_total, p);
-    HVLC_HIP(c, hipGetLastError());
+    HVLC_HIP(c, launch(k_exclusive_scan, dim3((unsigned)grid), dim3(kThreads), 0, s, d_counts, n, d_offsets, d_total, p));
     return HVLC_OK;
 }
 
@@ -461,8 +482,7 @@ int hvlc_rebase_offsets(hvlc_ctx* c, uint64_t* d_offsets, uint64_t n, uint64_t b
     HVLC_HIP(c, hipSetDevice(c->device));
     uint64_t grid = (n + kThreads - 1) / kThreads;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_rebase, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream, d_offsets, n, base_bits);
-    HVLC_HIP(c, hipGetLastError());
+    HVLC_HIP(c, launch(k_rebase, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream, d_offsets, n, base_bits));
     return HVLC_OK;
 }
 
@@ -474,9 +494,8 @@ int hvlc_rebase_offsets_dev(hvlc_ctx* c, uint64_t* d_offsets, uint64_t n,
     HVLC_HIP(c, hipSetDevice(c->device));
     uint64_t grid = (n + kThreads - 1) / kThreads;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_rebase_dev, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
-                       d_offsets, n, d_shard_totals, rank);
-    HVLC_HIP(c, hipGetLastError());
+    HVLC_HIP(c, launch(k_rebase_dev, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
+                       d_offsets, n, d_shard_totals, rank));
     return HVLC_OK;
 }
 
@@ -554,9 +573,8 @@ int hvlc_merge_shard(hvlc_ctx* c, const uint32_t* d_src_bits, uint64_t nbits, ui
     uint64_t grid = (nd / 4 + kThreads) / kThreads;          // one thread per four destination words
     const uint64_t cap = (uint64_t)c->cus * 32;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(k_merge_shard, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
-                       d_src_bits, nbits, d_dst_bits, dst_bit_offset);
-    HVLC_HIP(c, hipGetLastError());
+    HVLC_HIP(c, launch(k_merge_shard, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
+                       d_src_bits, nbits, d_dst_bits, dst_bit_offset));
     return HVLC_OK;
 }
 
@@ -571,9 +589,8 @@ int hvlc_decode(hvlc_ctx* c, const uint32_t* d_bits, uint64_t total_bits, const 
     uint64_t grid = (segs + kThreads - 1) / kThreads;
     const uint64_t cap = (uint64_t)c->cus * 4;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(k_decode, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
-                       d_bits, total_bits, d_offsets, segs, d_codewords, d_codewordlens, d_out_words, num_words);
-    HVLC_HIP(c, hipGetLastError());
+    HVLC_HIP(c, launch(k_decode, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
+                       d_bits, total_bits, d_offsets, segs, d_codewords, d_codewordlens, d_out_words, num_words));
     return HVLC_OK;
 }
 
@@ -588,9 +605,8 @@ int hvlc_gen_symbols(hvlc_ctx* c, uint8_t* d_out, uint64_t n_bytes, uint64_t see
     if (grid < 1) grid = 1;
     const uint64_t cap = (uint64_t)c->cus * 32;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(k_gen_symbols, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
-                       (uint32_t*)d_out, words, n_bytes & 3u, seed, first_draw, d_cdf32);
-    HVLC_HIP(c, hipGetLastError());
+    HVLC_HIP(c, launch(k_gen_symbols, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
+                       (uint32_t*)d_out, words, n_bytes & 3u, seed, first_draw, d_cdf32));
     return HVLC_OK;
 }
 
@@ -607,9 +623,8 @@ int hvlc_histogram(hvlc_ctx* c, const uint8_t* d_data, uint64_t n_bytes, uint64_
     if (grid < need) grid = need;
     const uint64_t maxb = (n_bytes / 16 + kThreads - 1) / kThreads + 1;
     if (grid > maxb) grid = maxb;
-    hipLaunchKernelGGL(k_histogram, dim3((unsigned)grid), dim3(kThreads), 0, s, d_data, n_bytes,
-                       (unsigned long long*)d_hist);
-    HVLC_HIP(c, hipGetLastError());
+    HVLC_HIP(c, launch(k_histogram, dim3((unsigned)grid), dim3(kThreads), 0, s, d_data, n_bytes,
+                       (unsigned long long*)d_hist));
     return HVLC_OK;
 }
 

@@ -10,39 +10,39 @@
 // Decomposition (all names follow the reference's domain):
 //   segment  256 input words = 1024 symbols  = ONE WAVE-ROW (64 lanes x 16 bytes);
 //            the reference's block (main_test_cu.cu:43); unit of out_offsets
-//   tile     28 segments = 28 KiB            = one pass of a workgroup's 7 data waves;
-//            data wave w owns the tile's segments 4w..4w+3 (4 KiB contiguous)
+//   part     4 segments = 4 KiB              = what ONE data wave encodes per tile
+//   tile     28 segments = 28 KiB            = the 7 parts of a workgroup's 7 data waves;
+//            data wave w owns the tile's segments 4w..4w+3; unit of the look-back
 //   group    64 tiles = 1.75 MiB             = unit of the second scan level
 //
 // Workgroup = 7 DATA waves + 1 SCOUT wave (two waves per SIMD), three workgroups per CU.
-// Data waves, per tile: (1) coalesced non-temporal dwordx4 loads (next tile
-// prefetched); (2) per-lane LDS table lookups (one SDWA op per address) and 64-bit
-// concatenation of 16 symbols; (3) wave64 DPP prefix scan of the bit lengths per
-// segment, wave totals through LDS; (4) the tile's bit count is PUBLISHED (one
-// self-validating word, relaxed agent-scope store); (5) "pabio": each lane ORs its
-// <=64 bits into the workgroup's LDS staging ring with 3 ds_or_b32 at TILE-LOCAL
-// bit positions (so packing does not wait for the global offset); (7) once the
-// scout has seen the tile's global bit offset, the tile's ring words are
-// funnel-shifted (v_alignbit_b32) by offset%32 and stored with coalesced dword
-// stores; segment offsets are written as uint64.
-// Scout wave: draws the workgroup's tiles from ticket counters, and (6) polls ONE
-// 16-byte record per tile in flight (global offset + the predecessor's <=31 carry
-// bits).  The offsets come from a two-level scan: the scout of the LAST tile of each
-// 64-tile group reads the group's 64 bit counts, publishes the group aggregate,
-// walks the group granules down to the nearest inclusive prefix and writes the
-// offsets of all 64 tiles into their records.  The scout exists because VMEM
-// retires in order per wave: a data wave polling other workgroups' words would
+// The data waves never wait for each other (no barrier after the LDS set-up).  A data wave, per
+// tile: (1) coalesced non-temporal dwordx4 loads (next tile prefetched); (2) per-lane LDS table
+// lookups (one SDWA op per address) and 64-bit concatenation of 16 symbols; (3) wave64 DPP
+// prefix scan of the bit lengths per segment; (4) it ARRIVES at the tile (one LDS atomic add of
+// its bit count): the last wave to arrive PUBLISHES the tile's bit count (one self-validating
+// word, relaxed agent-scope store); (5) "pabio": each lane ORs its <=64 bits into the wave's
+// OWN LDS staging ring with 3 ds_or_b32 at PART-LOCAL bit positions (so packing waits for
+// nothing); (7) several tiles later, once the scout has seen the tile's global bit offset, the
+// part's ring words are funnel-shifted (v_alignbit_b32) by offset%32 and stored with coalesced
+// dword stores; segment offsets are written as uint64.
+// Scout wave: draws the workgroup's tiles from ticket counters, and (6) polls ONE 16-byte record
+// per tile in flight (global offset + the predecessor's <=31 carry bits).  The offsets come
+// from a two-level scan: the scout of the LAST tile of each 64-tile group reads the group's 64
+// bit counts, publishes the group aggregate, walks the group granules down to the nearest
+// inclusive prefix and writes the offsets of all 64 tiles into their records.  The scout exists
+// because VMEM retires in order per wave: a data wave polling other workgroups' words would
 // drain its own prefetch and stores first.
 //
-// Forward progress: tiles are drawn only by RUNNING workgroups (dynamic tickets, 64
-// classes so that a workgroup never holds two tiles of one group), workgroups work
-// through their tiles in increasing order, and a tile depends only on tiles with
-// lower numbers plus its group's last tile -- so the encoder finishes whatever part
-// of the grid is resident.  Every wait is still bounded (s_memrealtime) and ends in
-// HVLC_ERR_TIMEOUT instead of a hang.  Inter-workgroup data are single naturally
-// aligned words carrying their own valid bit, written once and read with relaxed
-// agent-scope (sc1) accesses -- the form the CDNA4 guide lists as needing no
-// release/acquire fence -- and zeroed before each launch by k_prepare.
+// Forward progress: tiles are drawn only by RUNNING workgroups (dynamic tickets, 64 classes so
+// that a workgroup never holds two tiles of one group), every wave works through the workgroup's
+// tiles in increasing order, and a tile depends only on tiles with lower numbers plus its
+// group's last tile -- so the encoder finishes whatever part of the grid is resident.  Every
+// wait is still bounded (s_memrealtime) and ends in HVLC_ERR_TIMEOUT instead of a hang.
+// Inter-workgroup data are single naturally aligned 4- or 8-byte words carrying their own valid
+// bit, written once with ONE store and read by ONE lane with ONE load of the same width
+// (relaxed agent-scope, sc1) -- the form the CDNA4 guide lists as needing no release/acquire
+// fence -- and zeroed before each launch by k_prepare.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -67,38 +67,22 @@ constexpr int      kSegWords    = 256;
 constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 28: wave w owns segments 4w..4w+3
 constexpr int      kGroupTiles  = 64;
 constexpr int      kScanTile    = 4096;                    // elements per workgroup pass of k_exclusive_scan
-// LDS staging ring: a packed tile waits here, at tile-local bit positions, until its global offset is known.
-// A tile takes exactly the words it needs (carry word + ceil(bits/32) + pad, rounded to 16 bytes), so 3 tiles
-// of 4-bit-per-symbol data (14 KiB each) are in flight, or kMaxIn of anything that compresses better.
-#ifndef HVLC_RING_WORDS
-#define HVLC_RING_WORDS 12288
-#endif
-constexpr uint32_t kRingWords   = HVLC_RING_WORDS;         // 48 KiB: three 8-wave workgroups per CU
-#ifndef HVLC_MAX_INFLIGHT
-#define HVLC_MAX_INFLIGHT 4
-#endif
-constexpr int      kMaxIn       = HVLC_MAX_INFLIGHT;       // packed tiles in flight per workgroup (more only adds drift: measured)
-constexpr uint32_t kGeneralWords = (uint32_t)kDataThreads * 4u * 4u * 31u / 32u + 32u;   // general path: a part of a tile at 31 bits per symbol
-static_assert(kRingWords % 4 == 0 && kRingWords >= kGeneralWords, "the general path uses the ring as one buffer");
 #ifndef HVLC_TICKET_CLASSES
 #define HVLC_TICKET_CLASSES 64
 #endif
 constexpr int      kTicketClasses = HVLC_TICKET_CLASSES;    // ticket counters (workgroup b draws from counter b % kTicketClasses)
 constexpr int      kTicketStride  = 32;                    // uint32 words between counters (one 128-byte line each)
-#ifndef HVLC_TICKETS_AHEAD
-#define HVLC_TICKETS_AHEAD 2
-#endif
-constexpr int      kTq          = 8;                       // per-workgroup queue of drawn tile numbers (>= kMaxIn + 3)
 constexpr uint64_t kValid       = 1ull << 63;
 constexpr uint64_t kStAgg       = 1ull << 62;              // group granule: aggregate of the group
 constexpr uint64_t kStPre       = 2ull << 62;              // group granule: inclusive prefix through the group
 constexpr uint64_t kValMask     = (1ull << 62) - 1;
 
-// What a tile waits for, in one 16-byte record polled with ONE scalar load:
+// What a tile waits for, in one 16-byte record = two 8-byte words, each written by ONE store and polled by ONE
+// lane with ONE 8-byte load:
 //   P    = kValid | global exclusive bit offset of the tile, written by the LAST tile of the tile's
 //          group (the group leader) for all tiles of the group at once;
 //   tail = kValid32 | the last 31 bits of the stream before the tile, written by the tile before it
-//          (record 0: preset by k_prepare).
+//          (record 0: preset by k_prepare); `pad` is never written after k_prepare.
 struct alignas(16) TileRec { uint64_t P; uint32_t tail; uint32_t pad; };
 constexpr uint32_t kValid32 = 1u << 31;
 
@@ -108,7 +92,7 @@ struct EncodeParams {
     const uint4*    in;          // input words, 16-byte aligned
     uint64_t        num_words;
     uint64_t        num_tiles;
-    uint32_t        num_full_tiles;  // tiles that lie completely inside the input (num_words / 4096)
+    uint32_t        num_full_tiles;  // tiles that lie completely inside the input (num_words / kTileWords)
     uint64_t        num_segs;
     const uint2*    lut;         // {codeword (masked), length} x 256, built by k_prepare
     uint32_t*       out;         // final stream
@@ -125,7 +109,6 @@ struct EncodeParams {
     uint64_t        timeout_ticks;   // s_memrealtime ticks (100 MHz)
     uint32_t        stall_tile;      // TEST HOOK: this tile's bit count is never published (~0: none); see hvlc_api.hip
     uint32_t        dbg;             // ablation flags, honoured only in -DHVLC_EXPERIMENT builds (tools/)
-    uint64_t*       dbg_buf;         // phase stamps [grid][2][16], -DHVLC_EXPERIMENT builds only
     uint64_t*       dbg_tl;          // per-tile timeline [tiles][8] (100 MHz ticks), -DHVLC_EXPERIMENT builds only
 };
 
@@ -133,35 +116,12 @@ struct EncodeParams {
 enum : uint32_t { kDbgNoLookback = 1u, kDbgNoStore = 2u, kDbgNoPack = 4u, kDbgNoLookup = 8u, kDbgNoOffsets = 16u };
 #ifdef HVLC_EXPERIMENT
 #define HVLC_DBG(p, bit) (((p).dbg & (bit)) != 0u)
-// diagnostic phase timer (never in the product build): accumulates s_memtime deltas per phase
-struct Stamps {
-    uint64_t last, acc[16];
-#ifdef HVLC_NO_CLOCK      // counters only (keeps the register footprint of the product build)
-    __device__ __forceinline__ void init() { for (int i = 0; i < 16; ++i) acc[i] = 0; last = 0; }
-    __device__ __forceinline__ void lap(int) { }
-#else
-    __device__ __forceinline__ void init() { for (int i = 0; i < 16; ++i) acc[i] = 0; last = clock64(); }
-    __device__ __forceinline__ void lap(int i) { const uint64_t t = clock64(); acc[i] += t - last; last = t; }
-#endif
-    __device__ __forceinline__ void count(int i, uint64_t v = 1) { acc[i] += v; }
-    __device__ __forceinline__ void dump(uint64_t* buf, int which) {
-        if (buf) for (int i = 0; i < 16; ++i) buf[((uint64_t)blockIdx.x * 2 + which) * 16 + i] = acc[i];
-    }
-};
-#define STAMP_DECL Stamps stamps; stamps.init()
-#define STAMP(i) stamps.lap(i)
-#define STAMP_COUNT(i, v) stamps.count(i, v)
-#define STAMP_DUMP(buf, which, cond) do { if (cond) stamps.dump(buf, which); } while (0)
 #define TL(p, tile, k, cond) do { if ((p).dbg_tl && (cond)) (p).dbg_tl[(uint64_t)(tile) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define TLV(p, tile, k, v, cond) do { if ((p).dbg_tl && (cond)) (p).dbg_tl[(uint64_t)(tile) * 8 + (k)] = (v); } while (0)
 #else
 #define TL(p, tile, k, cond)
 #define TLV(p, tile, k, v, cond)
 #define HVLC_DBG(p, bit) false
-#define STAMP_DECL
-#define STAMP(i)
-#define STAMP_COUNT(i, v)
-#define STAMP_DUMP(buf, which, cond)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -190,25 +150,6 @@ __device__ __forceinline__ void st_word(uint32_t* p, uint32_t v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One polling round of the scout: ONE vector sc1 load instruction fetches the 16-byte records of up to six
-// tiles (lanes 0-23, a dword each) and, for a group leader, 16 group granules (lanes 32-63); the values are
-// moved to SGPRs (v_readlane) so that everything the scout decides is scalar code.
-// (Polling through the scalar memory path -- s_load ... glc -- was measured too: half the hand-off latency
-// with two pollers (tools/ubench.hip), but with 1535 scouts polling the scalar caches serialise their misses
-// and the kernel ran 15x slower.)
-constexpr int kMaxSlots = 6;       // records the scout can poll per round
-constexpr int kWindow   = 16;      // group granules a leader looks at per round (lanes 32..63 of the poll)
-// rec_off: per lane, the byte offset (from p.recs) of the dword this lane polls: lane 4s+k -> dword k of slot s's record
-template <bool WINDOW>
-__device__ __forceinline__ uint32_t poll_round(const EncodeParams& p, uint32_t rec_off, const void* w, int lane)
-{
-    const char* src = (const char*)p.recs + rec_off;
-    if (WINDOW && lane >= 32) src = (const char*)w + (uint32_t)(lane - 32) * 4u;   // lanes 32..63: the 32 dwords of the window
-    uint32_t v = 0;
-    if (lane < 4 * kMaxIn || (WINDOW && lane >= 32))
-        v = __hip_atomic_load((const uint32_t*)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return v;
-}
 __device__ __forceinline__ uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
@@ -406,51 +347,63 @@ __device__ __forceinline__ void put_row_pairs_mem(uint32_t* st, uint32_t q, cons
     }
 }
 
-// Per-tile state that lives from the iteration that packs a tile to the iteration that stores it.
-struct TileState {
-    uint64_t prefix;        // global exclusive bit offset (look-back result)
-    uint32_t bits;          // T: bits of the tile
-    uint32_t pred_tail;     // last 31 bits of the stream before the tile
-    uint32_t flags;         // kTsEarlyTail | kTsPrefixReady
-    uint32_t start, need;   // the tile's words in the staging ring: [start, start + need), start = its carry word
-    uint32_t seg_rel[kSegsPerTile];   // tile-local bit offset of each segment
+// ---------------------------------------------------------------------------------------------
+// LDS of an encoder workgroup.
+//
+// The DATA WAVES NEVER WAIT FOR EACH OTHER: wave w owns segments 4w..4w+3 of every tile of its workgroup (its
+// PART of the tile), packs them into its OWN staging ring at part-local bit positions and stores them, several
+// tiles later, once the scout has seen the tile's global bit offset.  What the waves of a workgroup tell each
+// other goes through small LDS records, written once per (tile, wave) and never waited for on the fast path:
+//   WaveRec  per (slot, wave)   bits of the part, its last 31 stream bits, where it sits in the ring
+//   TileSlot per slot           arrival counter + bit sum (the LAST wave to arrive publishes the tile's bit count
+//                               and every part's base), and the scout's result (global offset, predecessor tail)
+// A workgroup's n-th tile uses slot n % kSlots; a slot is reused only after every wave has stored its part of
+// the slot's previous tile (Smem::stored[]), so the fastest wave runs at most kSlots-1 tiles ahead of the slowest.
+// ---------------------------------------------------------------------------------------------
+constexpr int      kSlots   = 8;
+constexpr int      kTq      = 16;                          // queue of drawn tile numbers: workgroup-local tile n at [n % kTq]
+#ifndef HVLC_TICKETS_AHEAD
+#define HVLC_TICKETS_AHEAD 1
+#endif
+constexpr int      kTixAhead = HVLC_TICKETS_AHEAD;         // tiles the scout draws ahead of the fastest data wave
+static_assert(kTq >= kSlots + kTixAhead + 2, "a tile number must stay in the queue until every wave has stored the tile");
+#ifndef HVLC_WAVE_RING_WORDS
+#define HVLC_WAVE_RING_WORDS 1752
+#endif
+constexpr uint32_t kWaveRing = HVLC_WAVE_RING_WORDS;       // staging ring of ONE data wave: 7 x 6.8 KiB per workgroup, three workgroups per CU
+constexpr uint32_t kNoRoom   = 0xffffffffu;
+constexpr uint32_t kRowWordsMax = 1024u * 31u / 32u + 8u;  // slow path: one segment at 31 bits per symbol + carry word + read-ahead
+static_assert(kWaveRing % 4 == 0 && kWaveRing >= kRowWordsMax, "the slow path stages one segment in the (empty) ring");
+
+struct alignas(16) WaveRec {
+    uint32_t bits;            // T_w: bits of this wave's part of the tile
+    uint32_t tail;            // kValid32 | the last 31 stream bits up to the end of the part; 0 until known
+    uint32_t start, need;     // ring words [start, start + need) hold the packed part; start = its carry word
+    uint32_t base;            // bits of the tile in front of the part (written by the tile's last arriver)
+    uint32_t rb1, rb2, rb3;   // bit offsets of segments 1..3 inside the part (segment 0 starts at 0)
 };
-enum : uint32_t { kTsEarlyTail = 1u, kTsPrefixReady = 2u };
+struct alignas(16) TileSlot {
+    uint64_t prefix;          // scout: global exclusive bit offset of the tile
+    uint32_t pred_tail;       // scout: the last 31 bits of the stream before the tile
+    uint32_t arrive;          // data waves: (arrivals << 24) | bits so far (a tile holds < 2^20 bits)
+};
 
 struct alignas(16) Smem {
-    uint2     lut[256];                     // 2 KiB: {codeword, length}
-    uint32_t  ring[kRingWords];             // staging ring (see kRingWords)
-    uint32_t  wave_tot[kDataWaves];         // per-wave bit totals of the tile being packed
-    TileState ts[kMaxIn];                   // tile n of the workgroup uses ts[n % kMaxIn]
-    uint32_t  qtot[kDataWaves];             // general path: per-wave totals of a quarter tile
-    uint32_t  n_resolved;                   // scout -> data: tiles whose global offset is known (in order)
-    uint32_t  n_bits_pub;                   // data -> scout: tiles whose bit count is published (a leader's duty may start)
-    uint32_t  n_packed_pub;                 // data -> scout: tiles whose ts[] entry is complete (their record may be polled)
-    uint32_t  tq[kTq];                      // scout -> data: tile number of the workgroup's n-th tile, at [n % kTq]
-    uint32_t  n_tickets;                    // scout -> data: tiles drawn so far (release)
-    uint32_t  n_final;                      // scout -> data: the workgroup's tile count once the tickets ran out, else ~0
-    uint32_t  n_tix_snap, n_final_snap;     // data waves: per-iteration snapshots (uniform decisions)
-    uint32_t  tix_snap;                     // ... and the ticket count sampled before barrier 1
-    uint32_t  n_res_snap;                   // data waves: per-iteration snapshot of n_resolved (uniform decisions)
-    uint32_t  abort_snap;                   // ... and of abort_flag: all data waves must leave in the same iteration
-    uint32_t  bar;                          // arrival counter of the data waves' LDS barrier
+    uint2     lut[256];                       // 2 KiB: {codeword, length}; MUST be first (lut_at() addresses it absolutely)
+    uint32_t  ring[kDataWaves][kWaveRing];    // per-wave staging rings
+    WaveRec   wrec[kSlots][kDataWaves];
+    TileSlot  ts[kSlots];
+    uint32_t  stored[8];                      // data wave w: parts stored so far (slot reuse gate)
+    uint32_t  tq[kTq];                        // scout -> data: tile number of the workgroup's n-th tile
+    uint32_t  n_tickets;                      // scout -> data: tiles drawn so far (release)
+    uint32_t  n_final;                        // scout -> data: the workgroup's tile count once the tickets ran out, else ~0
+    uint32_t  n_resolved;                     // scout -> data: tiles whose global offset is known (in order)
+    uint32_t  n_bits_pub;                     // data -> scout: tiles whose bit count is published (in order; atomic max)
+    uint32_t  n_load_max;                     // data -> scout: tiles some data wave has started to load (atomic max)
     uint32_t  abort_flag;
+    uint32_t  pad_[2];
 };
-
-// Barrier among the DATA waves only, through an LDS counter: the scout wave never takes part, so a
-// granule round trip it is waiting for can never stall the data path (s_barrier would include it).
-// LDS operations of one wave complete in order, so a wave that sees all arrivals also sees
-// everything the others wrote to LDS before arriving.
-struct DataBarrier {
-    uint32_t target = 0;
-    __device__ __forceinline__ void sync(Smem& sm, int lane)
-    {
-        target += (uint32_t)kDataWaves;
-        if (lane == 0) (void)__hip_atomic_fetch_add(&sm.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(&sm.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
-            __builtin_amdgcn_s_sleep(1);                  // a spinning wave must not take issue slots from the working ones
-    }
-};
+static_assert(kDataWaves <= 8, "Smem::stored[] and the arrival counter hold up to 8 data waves");
 
 // Granule values a look-back may bring along (k_exclusive_scan passes none).
 struct LbRegs {
@@ -458,22 +411,21 @@ struct LbRegs {
     uint64_t v = 0;     // group_desc of group g-1-lane
 };
 
-// Two-level decoupled look-back, executed by ONE wave with all 64 lanes active.
-// Level 1: lanes 0..r-1 read the bit counts of the r predecessors inside the tile's group.
+// Two-level decoupled look-back, executed by ONE wave with all 64 lanes active (k_exclusive_scan).
+// Level 1: lanes 0..r-1 read the sums of the r predecessors inside the tile's group.
 // Level 2: lanes read the granules of up to 64 preceding groups; the nearest inclusive prefix
 //          plus the aggregates after it give the group's exclusive prefix.  The last tile of a
 //          group (the "leader") publishes the group's aggregate as soon as level 1 is done and its
 //          inclusive prefix after level 2, so one hop covers 64 tiles / 64 groups.
-// `L` may carry values loaded earlier (or zeros: everything is polled here).
+// Every granule is ONE naturally aligned 8-byte word read by ONE lane with ONE 8-byte load.
 template <bool WIDE>
 __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, uint64_t T, int lane, LbRegs L,
-                                         uint64_t& P_out, uint32_t& pred_tail)
+                                         uint64_t& P_out)
 {
     const uint32_t r = (uint32_t)(tile & (kGroupTiles - 1));
     const uint64_t g = tile / kGroupTiles;
     const bool leader = (r == kGroupTiles - 1) || (tile == p.num_tiles - 1);
     Spin spin;
-    if (HVLC_DBG(p, kDbgNoLookback)) { P_out = tile * 36400ull; pred_tail = 0; return true; }
 
     uint64_t d = L.d;
     const bool need = (uint32_t)lane < r;
@@ -484,7 +436,6 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
         if (!__any(need && !(d >> 63))) break;
         if (!spin.wait(p)) return false;
     }
-    // encoder tiles hold < 2^20 bits each (32-bit sum is exact); the scan's tiles may hold 62 bits
     const uint64_t insum = WIDE ? wave_sum_u64(need ? (d & kValMask) : 0ull)
                                 : (uint64_t)wave_sum_u32(need ? (uint32_t)d : 0u);
     if (leader && lane == 0) st_granule(&p.group_desc[g], kStAgg | ((insum + T) & kValMask));
@@ -515,40 +466,11 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
     }
     const uint64_t P = excl + insum;
     if (leader && lane == 0) st_granule(&p.group_desc[g], kStPre | ((P + T) & kValMask));
-
-    const uint32_t pt = 0;
     P_out = P;
-    pred_tail = pt;
     return true;
 }
 
-// Funnel-shift the staging buffer by s = (global bit offset % 32) and store `nown` finished words
-// at out[ow..].  sb[0] is the carry slot (low s bits = last s bits of the preceding stream).
-__device__ __forceinline__ void store_words(const EncodeParams& p, const uint32_t* sb, uint32_t s,
-                                            uint64_t ow, uint32_t nown, int tid)
-{
-    // capacity: decided once per call (all arguments are wave-uniform), not per word
-    if (ow + nown > p.out_cap) {
-        if (tid == 0) atomicOr(p.status, kFlagCapacity);
-        nown = ow < p.out_cap ? (uint32_t)(p.out_cap - ow) : 0u;
-    }
-    if (HVLC_DBG(p, kDbgNoStore)) return;
-    uint32_t* const dst = p.out + ow;                           // scalar base, 32-bit per-lane offsets
-    // one word per lane and trip: consecutive lanes read consecutive LDS words (no bank conflicts; four words per
-    // lane and a dwordx4 store were measured: fewer instructions, but 8-way conflicts on the strided LDS reads)
-    // (plain stores: non-temporal ones gained 7 % in the decoupled data-path experiment, tools/ubench_datapath.hip, but
-    // nothing here, where neighbouring tiles share the lines at their seams)
-    for (uint32_t k = (uint32_t)tid; k < nown; k += kDataThreads)
-        dst[k] = __builtin_amdgcn_alignbit(sb[k], sb[k + 1], s);
-}
-
-__device__ __forceinline__ void zero_words(uint32_t* base, uint32_t n_vec4, int tid)
-{
-    uint4* z = (uint4*)base;
-    for (uint32_t i = (uint32_t)tid; i < n_vec4; i += kDataThreads) z[i] = make_uint4(0, 0, 0, 0);
-}
-
-// Loads of one tile: lane-row r of wave w = segment 4w+r, 16 bytes per lane, 1 KiB per wave-instruction,
+// Loads of one wave's part of a tile: lane-row r = segment 4w+r, 16 bytes per lane, 1 KiB per wave-instruction,
 // non-temporal (the input is read exactly once).  `full` must be wave-uniform (a scalar branch): the
 // four loads of a full tile are issued back to back with nothing between them.
 __device__ __forceinline__ void load_tile(const EncodeParams& p, uint32_t tile, bool full, int wave, int lane,
@@ -582,371 +504,442 @@ __device__ __forceinline__ int valid_words(const EncodeParams& p, uint64_t wbase
     return wbase >= p.num_words ? 0 : (p.num_words - wbase >= 4 ? 4 : (int)(p.num_words - wbase));
 }
 
-// Store the finished words of a packed tile (fast path) and everything that needs its global
-// offset: segment offsets, the total on the last tile, the tail granule when it could not be
-// published early.
-__device__ __forceinline__ void finish_tile(const EncodeParams& p, Smem& sm, uint64_t tile, uint32_t par, int tid)
+// Funnel-shift staged words by s = (global bit offset % 32) and store `nown` finished words at out[ow..], by ONE
+// wave.  sb[0] is the carry slot (low s bits = last s bits of the preceding stream).
+__device__ __forceinline__ void store_words(const EncodeParams& p, const uint32_t* sb, uint32_t s,
+                                            uint64_t ow, uint32_t nown, int lane)
 {
-    const TileState& ts = sm.ts[par];
-    const uint64_t P = uni64(ts.prefix);
-    const uint32_t T = uni(ts.bits);
-    const bool last = (tile == p.num_tiles - 1);
-    const uint32_t* sb = sm.ring + uni(ts.start);
-    if (p.offsets && tid < kSegsPerTile && !HVLC_DBG(p, kDbgNoOffsets)) {
-        const uint64_t seg = tile * kSegsPerTile + (uint64_t)tid;
-        if (seg < p.num_segs) p.offsets[seg] = P + ts.seg_rel[tid];
+    // capacity: decided once per call (all arguments are wave-uniform), not per word
+    if (ow + nown > p.out_cap) {
+        if (lane == 0) atomicOr(p.status, kFlagCapacity);
+        nown = ow < p.out_cap ? (uint32_t)(p.out_cap - ow) : 0u;
     }
-    if (last && tid == 0) {
-        p.result[0] = P + T;
-        if (p.total_bits) *p.total_bits = P + T;
+    if (HVLC_DBG(p, kDbgNoStore)) return;
+    uint32_t* const dst = p.out + ow;                           // scalar base, 32-bit per-lane offsets
+    // one word per lane and trip: consecutive lanes read consecutive LDS words (no bank conflicts) and store 256
+    // contiguous bytes per wave-instruction
+    for (uint32_t k = (uint32_t)lane; k < nown; k += 64u)
+        dst[k] = __builtin_amdgcn_alignbit(sb[k], sb[k + 1], s);
+}
+
+__device__ __forceinline__ void zero_words(uint32_t* base, uint32_t n_vec4, int lane)
+{
+    uint4* z = (uint4*)base;
+    for (uint32_t i = (uint32_t)lane; i < n_vec4; i += 64u) z[i] = make_uint4(0, 0, 0, 0);
+}
+
+// LDS words shared between the waves of a workgroup: relaxed / acquire / release at WORKGROUP scope (LDS
+// operations of one wave complete in order; the scopes only keep the compiler from reordering them).
+__device__ __forceinline__ uint32_t lds_acq(const uint32_t* p) { return uni(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+__device__ __forceinline__ uint32_t lds_rlx(const uint32_t* p) { return uni(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+__device__ __forceinline__ void lds_rel(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// One bounded waiting step of a data wave: false = the launch is being aborted (timeout somewhere).
+struct WaveWait {
+    Spin spin;
+    __device__ __forceinline__ bool step(const EncodeParams& p, Smem& sm, int lane)
+    {
+        if (lds_rlx(&sm.abort_flag)) return false;
+        if (!spin.wait(p)) {
+            if (lane == 0) __hip_atomic_store(&sm.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return false;
+        }
+        return true;
     }
-    // the last tile also stores the open word, zero padded, and the zero word cpu_vlc_encode leaves
-    // behind when the stream ends on a word boundary (cpuencode.cpp:39)
-    const uint32_t s = (uint32_t)P & 31u;
-    uint32_t nown = (s + T) >> 5;
-    if (last) nown = ((s + T + 31u) >> 5) + ((((s + T) & 31u) == 0u) ? 1u : 0u);
-    store_words(p, sb, s, P >> 5, nown, tid);
-    if (!(uni(ts.flags) & kTsEarlyTail) && tid == 0) {
-        const uint32_t own  = extract_tail(sb + 1, T);
-        const uint32_t tail = T >= 31u ? own : (((ts.pred_tail << T) | own) & 0x7fffffffu);
-        st_word(&p.recs[tile + 1].tail, kValid32 | tail);
+};
+
+// Per-wave control state of a data wave (all wave-uniform).
+struct WaveCtl {
+    uint32_t m_loaded = 0, m_packed = 0, m_stored = 0;   // workgroup-local tile indices: input loaded / part packed / part stored
+    uint32_t head = 0;                                    // staging ring: where the next part's words start
+};
+
+// Where `need` words fit in the wave's staging ring: kNoRoom = nowhere for now.  Allocations are contiguous (a part
+// that does not fit before the end of the ring starts over at word 0) and are released in order.
+__device__ __forceinline__ uint32_t ring_place(const WaveCtl& c, const Smem& sm, int wave, uint32_t need)
+{
+    if (c.m_packed == c.m_stored) return 0u;                                   // empty (need <= kWaveRing is the caller's business)
+    const uint32_t tail = uni(sm.wrec[c.m_stored % kSlots][wave].start);       // oldest part still in the ring
+    if (c.head > tail) {
+        if (c.head + need <= kWaveRing) return c.head;
+        return need <= tail ? 0u : kNoRoom;
+    }
+    return (c.head < tail && need <= tail - c.head) ? c.head : kNoRoom;         // head == tail with parts in flight: full
+}
+
+// The tail of a part once the tail of what precedes it is known: its own last 31 bits, or, if it is shorter,
+// the predecessor's bits shifted up with its own appended.
+__device__ __forceinline__ uint32_t chain_tail(uint32_t pred_tail, uint32_t own, uint32_t T)
+{
+    return T >= 31u ? own : (((pred_tail << T) | own) & 0x7fffffffu);
+}
+
+// Publish the stream tail behind (tile, wave)'s part: to the next wave of the workgroup through LDS, and, for the
+// tile's last part, to the next tile's record (read by that tile's scout).
+__device__ __forceinline__ void publish_tail(const EncodeParams& p, Smem& sm, uint32_t slot, int wave, uint32_t tile,
+                                             uint32_t tail, int lane)
+{
+    if (lane == 0) {
+        lds_rel(&sm.wrec[slot][wave].tail, kValid32 | tail);
+        if (wave == kDataWaves - 1) st_word(&p.recs[(uint64_t)tile + 1].tail, kValid32 | tail);
     }
 }
 
-// General path for one tile (some lane-row holds more than 64 bits; lengths up to 31 allow 496):
-// the tile is re-read (L2) and packed quarter by quarter (4 KiB = wave-contiguous segments 4q..4q+3,
-// at most kGeneralWords words) into the (empty) staging ring taken as one buffer, two symbols (<=62 bits)
-// per put_bits64.  The carry runs through the parts exactly as it runs through tiles.  Blocking:
-// the caller has no other tile in flight.  Leaves the ring zeroed.
-__device__ __forceinline__ void general_tile(const EncodeParams& p, Smem& sm, DataBarrier& bar, uint64_t tile,
-                                             uint32_t par, int tid, int lane, int wave)
+// The last 31 stream bits in front of (slot, wave)'s part of a RESOLVED tile: the tile's predecessor tail for wave 0,
+// else what wave-1 published for the tile (normally long ago, at pack time; it is late only when wave-1's part is
+// shorter than 31 bits or went through the slow path).  False = abort.
+__device__ __forceinline__ bool pred_tail_of(const EncodeParams& p, Smem& sm, uint32_t slot, int wave, int lane, uint32_t& pt)
 {
-    const TileState& ts = sm.ts[par];
-    const bool last = (tile == p.num_tiles - 1);
-    const uint64_t word0 = tile * (uint64_t)kTileWords;
-    uint32_t* const big = sm.ring;
-    uint64_t Pq    = ts.prefix;
-    uint32_t carry = ts.pred_tail;
-    const uint32_t T = ts.bits;
-    if (p.offsets && tid < kSegsPerTile) {
-        const uint64_t seg = tile * kSegsPerTile + (uint64_t)tid;
-        if (seg < p.num_segs) p.offsets[seg] = Pq + ts.seg_rel[tid];
+    if (wave == 0) { pt = uni(sm.ts[slot].pred_tail); return true; }
+    WaveWait w;
+    for (;;) {
+        const uint32_t v = lds_acq(&sm.wrec[slot][wave - 1].tail);
+        if (v & kValid32) { pt = v & 0x7fffffffu; return true; }
+        if (!w.step(p, sm, lane)) return false;
     }
-    if (last && tid == 0) {
-        p.result[0] = Pq + T;
-        if (p.total_bits) *p.total_bits = Pq + T;
+}
+
+// Store the packed part j (workgroup-local tile index) of this wave: everything that needs the tile's global
+// offset -- the finished words, the segment offsets, the total on the last part of the stream, a late tail.
+__device__ __forceinline__ bool store_part(const EncodeParams& p, Smem& sm, uint32_t* ring, uint32_t j, int wave, int lane)
+{
+    const uint32_t slot = j % kSlots;
+    const WaveRec& r = sm.wrec[slot][wave];
+    const uint4 ra = *reinterpret_cast<const uint4*>(&r.bits);      // bits, tail, start, need
+    const uint4 rb = *reinterpret_cast<const uint4*>(&r.base);      // base, rb1, rb2, rb3
+    const uint32_t T = uni(ra.x), own_tail = uni(ra.y), start = uni(ra.z), need = uni(ra.w);
+    const uint32_t tile = uni(sm.tq[j % kTq]);
+    const uint64_t G = uni64(sm.ts[slot].prefix) + (uint64_t)uni(rb.x);   // global bit offset of the part
+    uint32_t pt;
+    if (!pred_tail_of(p, sm, slot, wave, lane, pt)) return false;
+    uint32_t* const sb = ring + start;
+    if (lane == 0) sb[0] = pt;                                      // carry word (same-wave LDS operations complete in order)
+    TL(p, tile, 5, lane == 0 && wave == 0);
+    if (p.offsets && lane < kRows && !HVLC_DBG(p, kDbgNoOffsets)) {
+        const uint64_t seg = (uint64_t)tile * kSegsPerTile + (uint64_t)(wave * kRows + lane);
+        const uint32_t rel = lane == 0 ? 0u : lane == 1 ? rb.y : lane == 2 ? rb.z : rb.w;
+        if (seg < p.num_segs) p.offsets[seg] = G + rel;
     }
-    for (int qd = 0; qd < kRows; ++qd) {
-        bar.sync(sm, lane);                            // previous quarter fully stored
-        zero_words(big, kGeneralWords / 4u, tid);
-        const uint64_t wbase = word0 + (uint64_t)qd * (kDataThreads * 4u) + (uint64_t)tid * 4u;
-        const uint32_t* in32 = (const uint32_t*)p.in;
+    const bool last = (tile == (uint32_t)(p.num_tiles - 1)) && wave == kDataWaves - 1;
+    if (last && lane == 0) {
+        p.result[0] = G + T;
+        if (p.total_bits) *p.total_bits = G + T;
+    }
+    // the last part of the stream also stores the open word, zero padded, and the zero word cpu_vlc_encode leaves
+    // behind when the stream ends on a word boundary (cpuencode.cpp:39)
+    const uint32_t s = (uint32_t)G & 31u;
+    uint32_t nown = (s + T) >> 5;
+    if (last) nown = ((s + T + 31u) >> 5) + ((((s + T) & 31u) == 0u) ? 1u : 0u);
+    store_words(p, sb, s, G >> 5, nown, lane);
+    if (!(own_tail & kValid32))                                    // a part shorter than 31 bits: its tail needed the predecessor's
+        publish_tail(p, sm, slot, wave, tile, chain_tail(pt, extract_tail(sb + 1, T), T), lane);
+    zero_words(sb, need / 4u, lane);
+    return true;
+}
+
+// Slow path for ONE wave's part of a tile: the part does not fit the wave's (empty) ring (more than ~13 bits per
+// symbol), or the tile is the one the input ends in.  Runs with the ring drained and the tile resolved, segment by
+// segment: the segment is re-read (valid words only), packed two symbols (<=62 bits) per put_bits64 into the ring
+// taken as one buffer, funnel-shifted and stored; the carry runs through the segments exactly as it runs through
+// parts.  Leaves the ring zeroed.
+__device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint32_t* ring, uint32_t j, uint32_t tile,
+                                          int wave, int lane)
+{
+    const uint32_t slot = j % kSlots;
+    uint64_t G = uni64(sm.ts[slot].prefix) + (uint64_t)uni(sm.wrec[slot][wave].base);
+    uint32_t carry;
+    if (!pred_tail_of(p, sm, slot, wave, lane, carry)) return false;
+    const bool last_part = (tile == (uint32_t)(p.num_tiles - 1)) && wave == kDataWaves - 1;
+    const uint32_t* in32 = (const uint32_t*)p.in;
+#pragma unroll 1
+    for (int r = 0; r < kRows; ++r) {
+        const uint64_t seg   = (uint64_t)tile * kSegsPerTile + (uint64_t)(wave * kRows + r);
+        const uint64_t wbase = seg * kSegWords + (uint64_t)lane * 4u;
         const int n = valid_words(p, wbase);
         uint32_t w[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) w[k] = k < n ? in32[wbase + k] : 0u;
-        uint32_t tq = 0;
+        uint32_t t = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (k < n) {
                 const uint32_t h = hash4(w[k]);
 #pragma unroll
-                for (int b = 3; b >= 0; --b) tq += sm.lut[(h >> (8 * b)) & 255u].y;
+                for (int b = 3; b >= 0; --b) t += sm.lut[(h >> (8 * b)) & 255u].y;
             }
-        const uint32_t incl = wave_incl_scan(tq);
-        if (lane == 63) sm.qtot[wave] = incl;
-        bar.sync(sm, lane);
-        uint32_t Tq = 0, qbase = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < kDataWaves; ++w2) { const uint32_t q = sm.qtot[w2]; if (w2 < wave) qbase += q; Tq += q; }
-        const uint32_t pos = (incl - tq) + qbase;
-        if (tid == 0) big[0] = carry;
-        put_row_pairs(big + 1, pos, w, n, sm.lut);
-        bar.sync(sm, lane);
-        const uint32_t s = (uint32_t)Pq & 31u;
-        const bool lastq = last && qd == kRows - 1;
+        const uint32_t incl = wave_incl_scan(t);
+        const uint32_t Tq = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (p.offsets && lane == 0 && seg < p.num_segs) p.offsets[seg] = G;
+        if (lane == 0) ring[0] = carry;
+        put_row_pairs(ring + 1, incl - t, w, n, sm.lut);
+        const uint32_t s = (uint32_t)G & 31u;
+        const bool lastq = last_part && r == kRows - 1;
         uint32_t nown = (s + Tq) >> 5;
         if (lastq) nown = ((s + Tq + 31u) >> 5) + ((((s + Tq) & 31u) == 0u) ? 1u : 0u);
-        store_words(p, big, s, Pq >> 5, nown, tid);
-        const uint32_t own = extract_tail(big + 1, Tq);     // every thread computes the same carry
-        carry = Tq >= 31u ? own : (((carry << Tq) | own) & 0x7fffffffu);
-        Pq += Tq;
+        store_words(p, ring, s, G >> 5, nown, lane);
+        carry = chain_tail(carry, extract_tail(ring + 1, Tq), Tq);    // every lane computes the same carry
+        zero_words(ring, (((Tq + 31u) >> 5) + 8u) / 4u, lane);
+        G += Tq;
     }
-    bar.sync(sm, lane);
-    if (tid == 0) st_word(&p.recs[tile + 1].tail, kValid32 | carry);
-    zero_words(big, kGeneralWords / 4u, tid);
-}
-
-// Workgroup-uniform control state of the data waves' pipeline.
-// Tiles are handed out DYNAMICALLY: every tile a workgroup works on is drawn by its scout from one of
-// kTicketClasses atomic counters (draw k of class c is tile 64k + (c + k) % 64, so the classes interleave, the
-// group-leader role rotates over them and a workgroup never holds two tiles of one group).  A workgroup draws a tile only when it is about to work on it,
-// so (1) no tile ever waits for a workgroup that is not running: forward progress does not depend on the grid
-// being co-resident, and (2) a slow workgroup just draws fewer tiles instead of setting everybody's pace.
-// Tile numbers are limited to 28 bits by the host (32-bit record offsets): 7 TiB of input per call.
-struct RingCtl {
-    uint32_t n_packed = 0, n_stored = 0, n_res = 0;   // tiles packed / stored / resolved (workgroup-local numbering)
-    uint32_t n_loaded = 0;                            // tiles whose input loads have been issued (n_packed or n_packed + 1)
-    uint32_t n_tix = 0, n_final = ~0u;                // snapshots of Smem::n_tickets / n_final
-    uint32_t head = 0;                                // staging ring: where the next tile's words start
-    uint32_t last_need = 0;                           // words the previous tile took (predicts the next one)
-};
-
-// Where `need` words fit in the staging ring: kRingWords = nowhere for now.  Allocations are contiguous (a tile
-// that does not fit before the end of the ring starts over at word 0) and are released in order.
-// `n_stored` = tiles already released (the caller may count one that is being released in this iteration).
-__device__ __forceinline__ uint32_t ring_place(const RingCtl& c, const Smem& sm, uint32_t need, uint32_t n_stored)
-{
-    if (c.n_packed == n_stored) return 0u;                                 // empty (need <= kRingWords is the caller's business)
-    const uint32_t tail = uni(sm.ts[n_stored % kMaxIn].start);             // oldest tile still in the ring
-    if (c.head > tail) {
-        if (c.head + need <= kRingWords) return c.head;
-        return need <= tail ? 0u : kRingWords;
+    if (last_part && lane == 0) {
+        p.result[0] = G;
+        if (p.total_bits) *p.total_bits = G;
     }
-    return (c.head < tail && need <= tail - c.head) ? c.head : kRingWords;  // head == tail with tiles in flight: full
-}
-
-// One blocking step of the data waves while they cannot go on (ring full, or an oversized tile waiting for the
-// ring to drain): store the oldest tile if its offset is known, else sleep; refresh the scout's counters.
-// Returns false if the launch is being aborted.
-__device__ __forceinline__ bool drain_step(const EncodeParams& p, Smem& sm, DataBarrier& bar, RingCtl& c, uint32_t limit,
-                                           int tid, int lane)
-{
-    const bool st_old = c.n_stored < limit && c.n_stored < c.n_res;
-    const uint32_t ss = c.n_stored % kMaxIn;
-    if (st_old) finish_tile(p, sm, uni(sm.tq[c.n_stored % kTq]), ss, tid);
-    else        __builtin_amdgcn_s_sleep(8);
-    bar.sync(sm, lane);
-    if (st_old) zero_words(sm.ring + uni(sm.ts[ss].start), uni(sm.ts[ss].need) / 4u, tid);
-    if (tid == 0) {
-        sm.n_res_snap = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        sm.abort_snap = __hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    bar.sync(sm, lane);
-    if (uni(sm.abort_snap)) return false;
-    c.n_res = uni(sm.n_res_snap);
-    if (st_old) ++c.n_stored;
+    publish_tail(p, sm, slot, wave, tile, carry, lane);
     return true;
 }
 
 // ------------------------------------------------------------------------------------------------
-// DATA waves of the pipelined encoder.  One loop iteration:
-//   phase X  store the OLDEST packed tile if the scout has resolved its offset (funnel shift out of the
-//            staging ring, coalesced dword stores); look up / concatenate / scan the next tile (registers
-//            only) if the ring is likely to have room for it; issue the loads of the tile after it
-//   -- data barrier --
-//   phase Y  publish the new tile's bit count, take its words in the ring, pack it, publish its tail;
-//            clear the words of the tile that was just stored; thread 0 snapshots the scout's progress
-//   -- data barrier --
-// A tile that does not fit the ring even when it is empty (more than ~15 bits per symbol on average) takes
-// the general path once the ring has drained.
+// A DATA wave of the pipelined encoder.  One loop iteration = one tile of the workgroup, this wave's part:
+//   1  wait for the part's input (loaded during the previous iteration), look up / concatenate its 4 x 16 symbols
+//      per lane (registers only), DPP-scan the lane-row bit counts
+//   2  store the OLDEST packed part if the scout has resolved its tile (funnel shift out of the ring, coalesced
+//      dword stores) -- in front of the prefetch: vector-memory operations retire in order, so a store issued
+//      behind the prefetch loads would delay nothing, but a load wait behind a store waits for the store's
+//      acknowledgement; here the stores have a whole iteration to complete
+//   3  issue the loads of the next tile's part into the registers the lookups just vacated
+//   4  take the part's words in the ring, write its record, ARRIVE (the last wave to arrive publishes the tile's bit
+//      count), pack (three branch-free ds_or_b32 per lane-row), publish the part's tail
+// Waiting happens only for: a tile number (scout), ring space / a free slot (resolution of older tiles).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void encode_data_waves(const EncodeParams& p, Smem& sm, RingCtl c, int tid, int lane, int wave)
+__device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm, int lane, int wave)
 {
     uint4 raw[kRows];
 #pragma unroll
     for (int r = 0; r < kRows; ++r) raw[r] = make_uint4(0, 0, 0, 0);
-    DataBarrier bar;
-    STAMP_DECL;
+    uint32_t* const ring = sm.ring[wave];
+    WaveCtl c;
+    uint32_t n_final = ~0u;
 
-    while (c.n_stored < c.n_final) {
-        const bool have_raw = c.n_loaded > c.n_packed;
-        const bool do_store = c.n_stored < c.n_res;
-        const bool can_pack = have_raw && (c.n_packed - c.n_stored) < (uint32_t)kMaxIn &&        // probably fits (if the tile
-                              ring_place(c, sm, c.last_need, c.n_stored + (do_store ? 1u : 0u)) < kRingWords;   // is like the last one,
-                                                                                                 // and with what this iteration frees)
-        const uint32_t sp = c.n_packed % kMaxIn, ss = c.n_stored % kMaxIn;
-        const uint32_t cur = uni(sm.tq[c.n_packed % kTq]);                       // meaningful when have_raw
-        STAMP_COUNT(8, 1); STAMP_COUNT(9, can_pack ? 1 : 0); STAMP_COUNT(10, do_store ? 1 : 0);
-        STAMP_COUNT(11, (!can_pack && !do_store) ? 1 : 0);
+    // store the oldest packed part if its tile is resolved
+    auto try_store = [&]() -> int {      // 1 stored, 0 nothing to store, -1 abort
+        if (c.m_stored == c.m_packed) return 0;
+        if (lds_acq(&sm.n_resolved) <= c.m_stored) return 0;
+        if (!store_part(p, sm, ring, c.m_stored, wave, lane)) return -1;
+        ++c.m_stored;
+        if (lane == 0) lds_rel(&sm.stored[wave], c.m_stored);
+        if (c.m_stored == c.m_packed) c.head = 0;            // empty ring: start over at word 0
+        return 1;
+    };
+    // issue the loads of the workgroup's tile number c.m_loaded if the scout has drawn it
+    auto try_load = [&]() -> bool {
+        if (lds_acq(&sm.n_tickets) <= c.m_loaded) return false;
+        const uint32_t t = uni(sm.tq[c.m_loaded % kTq]);
+        load_tile(p, t, t < p.num_full_tiles, wave, lane, raw);
+        ++c.m_loaded;
+        if (lane == 0) (void)__hip_atomic_fetch_max(&sm.n_load_max, c.m_loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return true;
+    };
 
-        // ---------------- phase X ----------------
+    for (;;) {
+        // ---- input of the next tile: normally prefetched; at the start and when the scout was behind, wait here
+        if (c.m_loaded == c.m_packed) {
+            WaveWait w;
+            for (;;) {
+                if (n_final == ~0u) n_final = lds_rlx(&sm.n_final);      // (read BEFORE the ticket count: once set, every ticket is visible)
+                if (try_load()) break;
+                if (n_final != ~0u && c.m_loaded >= n_final) break;      // the tickets ran out
+                const int st = try_store();
+                if (st < 0) return;
+                if (st == 0 && !w.step(p, sm, lane)) return;
+            }
+        }
+        if (c.m_loaded == c.m_packed) {                                   // nothing left to encode: store what is packed and leave
+            WaveWait w;
+            while (c.m_stored < c.m_packed) {
+                const int st = try_store();
+                if (st < 0) return;
+                if (st == 0 && !w.step(p, sm, lane)) return;
+            }
+            return;
+        }
+        const uint32_t cur  = uni(sm.tq[c.m_packed % kTq]);
+        const uint32_t slot = c.m_packed % kSlots;
+        const bool full = cur < p.num_full_tiles;
+
+        // ---- 1: lookups, concatenation, scan (registers only)
         uint64_t acc[kRows];
         uint32_t tot[kRows], excl[kRows], rowbase[kRows];
-        STAMP(0);
-        STAMP(1);
-        if (can_pack) {
-            uint32_t wavetot = 0;
-            if (cur < p.num_full_tiles) {
+        if (full) {
 #pragma unroll
-                for (int r = 0; r < kRows; ++r) encode16<true>(raw[r], 4, sm.lut, acc[r], tot[r]);
-            } else {
-                // the one tile the input ends in: bit counts only, the general path packs it (cold code)
-#pragma unroll
-                for (int r = 0; r < kRows; ++r) {
-                    const uint64_t wbase = (uint64_t)cur * kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
-                    const int nv = valid_words(p, wbase);
-                    const uint32_t wd[4] = { raw[r].x, raw[r].y, raw[r].z, raw[r].w };
-                    uint32_t t = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < nv) {
-                            const uint32_t h = hash4(wd[k]);
-                            t += sm.lut[h >> 24].y + sm.lut[(h >> 16) & 255u].y + sm.lut[(h >> 8) & 255u].y + sm.lut[h & 255u].y;
-                        }
-                    tot[r] = t; acc[r] = 0;
-                }
-            }
+            for (int r = 0; r < kRows; ++r) encode16<true>(raw[r], 4, sm.lut, acc[r], tot[r]);
+        } else {
+            // the one tile the input ends in: bit counts only, the slow path packs it (cold code)
 #pragma unroll
             for (int r = 0; r < kRows; ++r) {
-                const uint32_t incl = wave_incl_scan(tot[r]);
-                excl[r]    = incl - tot[r];
-                rowbase[r] = wavetot;
-                wavetot   += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint64_t wbase = (uint64_t)cur * kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
+                const int nv = valid_words(p, wbase);
+                const uint32_t wd[4] = { raw[r].x, raw[r].y, raw[r].z, raw[r].w };
+                uint32_t t = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < nv) {
+                        const uint32_t h = hash4(wd[k]);
+                        t += sm.lut[h >> 24].y + sm.lut[(h >> 16) & 255u].y + sm.lut[(h >> 8) & 255u].y + sm.lut[h & 255u].y;
+                    }
+                tot[r] = t; acc[r] = 0;
             }
-            if (lane == 0) sm.wave_tot[wave] = wavetot;
-            STAMP(2);
         }
-        // The stream stores of the oldest tile go BEHIND the encode: vector-memory operations retire in order, and the
-        // encode starts by waiting for the tile's input loads -- stores issued in front of that wait would have to be
-        // acknowledged first (a write round trip exposed per tile); issued here they have until the next tile's wait.
-        if (do_store) {
-            const uint32_t st_tile = uni(sm.tq[c.n_stored % kTq]);
-            TL(p, st_tile, 5, tid == 0);
-            finish_tile(p, sm, st_tile, ss, tid);
+        uint32_t T = 0;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const uint32_t incl = wave_incl_scan(tot[r]);
+            excl[r]    = incl - tot[r];
+            rowbase[r] = T;
+            T         += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
-        if (!can_pack && !do_store) __builtin_amdgcn_s_sleep(8);   // nothing to do this round: wait for the scout
-        // the freshest ticket count, sampled by one thread right before the barrier: a tile drawn while this tile was
-        // being encoded can be loaded now instead of an iteration later (measured: a third of the iterations had no
-        // tile to encode when the count came from the previous iteration's snapshot)
-        if (tid == 0) sm.tix_snap = __hip_atomic_load(&sm.n_tickets, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        STAMP(3);
-        bar.sync(sm, lane);                                                   // data barrier 1
-        STAMP(4);
 
-        // ---------------- phase Y ----------------
-        c.n_tix = uni(sm.tix_snap);
-        if ((can_pack || !have_raw) && c.n_loaded < c.n_tix) {   // raw is dead or empty: its registers take the next drawn tile
-            const uint32_t nxt = uni(sm.tq[c.n_loaded % kTq]);
-            load_tile(p, nxt, nxt < p.num_full_tiles, wave, lane, raw);
-            ++c.n_loaded;
+        // ---- 2: the oldest part's stream stores, 3: the next tile's loads
+        if (try_store() < 0) return;
+        (void)try_load();
+
+        // ---- 4: slot, record, arrival, ring words
+        if (c.m_packed >= (uint32_t)kSlots) {                 // the slot's previous tile must be stored by every wave
+            const uint32_t floor_ = c.m_packed - (uint32_t)kSlots + 1u;
+            WaveWait w;
+            for (;;) {
+                const uint32_t v = lane < kDataWaves ? __hip_atomic_load(&sm.stored[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : ~0u;
+                if (!__any(v < floor_)) break;
+                const int st = try_store();
+                if (st < 0) return;
+                if (st == 0 && !w.step(p, sm, lane)) return;
+            }
         }
-        bool release = do_store;                           // every wave is past its part of the store: clear its words; they
-        if (release) zero_words(sm.ring + uni(sm.ts[ss].start), uni(sm.ts[ss].need) / 4u, tid);   // count as free after the next barrier
-        bool slow = false;
-        if (can_pack) {
-            uint32_t T = 0, wavebase = 0, clast = 0;
-#pragma unroll
-            for (int w2 = 0; w2 < kDataWaves; ++w2) { clast = uni(sm.wave_tot[w2]); if (w2 < wave) wavebase += clast; T += clast; }
-            if (tid == 0) {
-                if (cur != p.stall_tile) st_word(&p.bits32[cur], kValid32 | T);   // publish before anything else
-                TL(p, cur, 0, true);
-                // a group leader's scout starts on this alone, even if the tile has to wait for room in the ring
-                __hip_atomic_store(&sm.n_bits_pub, c.n_packed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            const uint32_t need = (((T + 31u) >> 5) + 2u + 3u) & ~3u;  // carry word + data + the word store_words reads ahead
-            slow = need > kRingWords || cur >= p.num_full_tiles;   // fits no ring, or the partial last tile: general path, once the ring is empty
-            uint32_t start = 0;
-            if (!slow) {
-                // rare: the tile is bigger than predicted and the ring has no room yet -- store older tiles until it has
-                while ((start = ring_place(c, sm, need, c.n_stored)) >= kRingWords) {
-                    if (release) { bar.sync(sm, lane); ++c.n_stored; release = false; continue; }
-                    if (!drain_step(p, sm, bar, c, c.n_packed, tid, lane)) return;
-                }
-                c.head = start + need;
-                c.last_need = need;
-            }
-            const bool early_tail = !slow && clast >= 31u;   // the tile's last 31 bits are all written by the last data wave
-            if (tid == 0) {
-                sm.ts[sp].bits  = T;
-                sm.ts[sp].flags = early_tail ? kTsEarlyTail : 0u;
-                sm.ts[sp].start = start;
-                sm.ts[sp].need  = slow ? 0u : need;
-                // the scout needs only this to poll the tile's record (it never reads the packed words)
-                __hip_atomic_store(&sm.n_packed_pub, c.n_packed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+        const uint32_t need = (((T + 31u) >> 5) + 3u + 3u) & ~3u;    // carry word + data + the two words behind the data that pack / store touch
+        const bool slow = !full || need > kWaveRing;
+        if (lane == 0) {
+            WaveRec& rec = sm.wrec[slot][wave];
+            *reinterpret_cast<uint2*>(&rec.bits) = make_uint2(T, 0u);                        // bits; tail not known yet
+            *reinterpret_cast<uint4*>(&rec.base) = make_uint4(0u, rowbase[1], rowbase[2], rowbase[3]);
+        }
+        // ARRIVE before anything that may wait: other workgroups wait for the tile's bit count.  (The record is written
+        // before the add: release; the last arriver reads the others' records: acquire.)
+        uint32_t old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(&sm.ts[slot].arrive, (1u << 24) | T, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = uni(old);
+        if ((old >> 24) == (uint32_t)(kDataWaves - 1)) {
+            // last to arrive: every part's base, the tile's bit count (what other workgroups wait for), slot counter reset
+            const uint32_t b    = lane < kDataWaves ? sm.wrec[slot][lane].bits : 0u;
+            const uint32_t incl = wave_incl_scan(b);
+            if (lane < kDataWaves) sm.wrec[slot][lane].base = incl - b;
+            const uint32_t Ttile = (uint32_t)__builtin_amdgcn_readlane((int)incl, kDataWaves - 1);
             if (lane == 0) {
-#pragma unroll
-                for (int r = 0; r < kRows; ++r) sm.ts[sp].seg_rel[wave * kRows + r] = wavebase + rowbase[r];
+                sm.ts[slot].arrive = 0u;
+                (void)__hip_atomic_fetch_max(&sm.n_bits_pub, c.m_packed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur != p.stall_tile) st_word(&p.bits32[cur], kValid32 | Ttile);
             }
-            if (!slow) {
-                uint32_t* const st = sm.ring + start + 1;
-                uint32_t big = 0;                            // rows of this lane with more than 64 bits (rare)
+            TL(p, cur, 0, lane == 0);
+        }
+        uint32_t start = 0;
+        if (!slow) {
+            WaveWait w;
+            while ((start = ring_place(c, sm, wave, need)) == kNoRoom) {   // no room yet: store older parts until there is
+                const int st = try_store();
+                if (st < 0) return;
+                if (st == 0 && !w.step(p, sm, lane)) return;
+            }
+            c.head = start + need;
+        }
+        if (lane == 0) *reinterpret_cast<uint2*>(&sm.wrec[slot][wave].start) = make_uint2(start, slow ? 0u : need);   // (read by this wave only)
+
+        // ---- 4b: pack
+        if (!slow) {
+            uint32_t* const st = ring + start + 1;
+            uint32_t big = 0;                            // rows of this lane with more than 64 bits (rare)
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                const uint32_t q = rowbase[r] + excl[r];
+                if (HVLC_DBG(p, kDbgNoPack)) { if (acc[r] == 0x123456789ull) st[q & 1023u] = tot[r]; continue; }
+                const bool fits = tot[r] <= 64u;
+                put_bits64_flat(st, q, fits ? acc[r] : 0ull, fits ? tot[r] : 0u);
+                big |= fits ? 0u : (1u << r);
+            }
+            if (__any(big != 0u)) {                      // cold: re-read such a lane-row (L2) and pack it pairwise
 #pragma unroll
                 for (int r = 0; r < kRows; ++r) {
-                    const uint32_t q = wavebase + rowbase[r] + excl[r];
-                    if (HVLC_DBG(p, kDbgNoPack)) { if (acc[r] == 0x123456789ull) st[q & 1023u] = tot[r]; continue; }
-                    const bool fits = tot[r] <= 64u;
-                    put_bits64_flat(st, q, fits ? acc[r] : 0ull, fits ? tot[r] : 0u);
-                    big |= fits ? 0u : (1u << r);
-                }
-                if (__any(big != 0u)) {                      // cold: re-read such a lane-row (L2) and pack it pairwise
-#pragma unroll
-                    for (int r = 0; r < kRows; ++r) {
-                        if ((big >> r) & 1u) {
-                            const char* base = (const char*)p.in + (uint64_t)cur * (uint64_t)(kTileWords * 4);
-                            put_row_pairs_mem(st, wavebase + rowbase[r] + excl[r],
-                                              (const uint32_t*)(base + (uint32_t)((wave * kRows + r) * 64 + lane) * 16u), sm.lut);
-                        }
+                    if ((big >> r) & 1u) {
+                        const char* base = (const char*)p.in + (uint64_t)cur * (uint64_t)(kTileWords * 4);
+                        put_row_pairs_mem(st, rowbase[r] + excl[r],
+                                          (const uint32_t*)(base + (uint32_t)((wave * kRows + r) * 64 + lane) * 16u), sm.lut);
                     }
                 }
-                if (early_tail && wave == kDataWaves - 1 && lane == 0)   // same-wave LDS ops complete in order
-                    st_word(&p.recs[(uint64_t)cur + 1].tail, kValid32 | extract_tail(st, T));
             }
-            ++c.n_packed;
-        }
-        STAMP(5);
-        if (tid == 0) {
-            sm.n_res_snap   = __hip_atomic_load(&sm.n_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            sm.abort_snap   = __hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            sm.n_final_snap = __hip_atomic_load(&sm.n_final, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            sm.n_tix_snap   = __hip_atomic_load(&sm.n_tickets, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        STAMP(6);
-        bar.sync(sm, lane);                                                   // data barrier 2
-        STAMP(7);
-        if (uni(sm.abort_snap)) return;                   // uniform: one thread sampled the flag before the barrier
-        c.n_res = uni(sm.n_res_snap); c.n_final = uni(sm.n_final_snap);
-        { const uint32_t t2 = uni(sm.n_tix_snap); if (t2 > c.n_tix) c.n_tix = t2; }
-        if (release) ++c.n_stored;
-        if (c.n_packed == c.n_stored) c.head = 0;         // empty ring: start over at word 0
-
-        if (slow) {
-            // Oversized tile: drain the ring (store every older tile), wait for its own offset, then encode
-            // it on the general path, which uses the whole (empty) ring and leaves it zeroed.
-            const uint32_t me = c.n_packed - 1;
-            while (!(c.n_stored == me && c.n_res > me))
-                if (!drain_step(p, sm, bar, c, me, tid, lane)) return;
-            general_tile(p, sm, bar, cur, sp, tid, lane, wave);
-            ++c.n_stored;
+            if (T >= 31u)                                // the part's last 31 bits are all its own: publish the tail now
+                publish_tail(p, sm, slot, wave, cur, extract_tail(st, T), lane);
+            ++c.m_packed;
+        } else {
+            // slow path: drain the ring, wait for this tile's offset, store the part directly
+            ++c.m_packed;
+            WaveWait w;
+            while (c.m_stored + 1u < c.m_packed) {
+                const int st = try_store();
+                if (st < 0) return;
+                if (st == 0 && !w.step(p, sm, lane)) return;
+            }
+            while (lds_acq(&sm.n_resolved) < c.m_packed)
+                if (!w.step(p, sm, lane)) return;
+            if (!slow_part(p, sm, ring, c.m_packed - 1u, cur, wave, lane)) return;
+            ++c.m_stored;
+            if (lane == 0) lds_rel(&sm.stored[wave], c.m_stored);
             c.head = 0;
-            bar.sync(sm, lane);
         }
     }
-    STAMP_DUMP(p.dbg_buf, 0, tid == 0);
 }
 
 // ------------------------------------------------------------------------------------------------
 // SCOUT wave: everything that crosses workgroups.  Its decisions are scalar code: what a tile waits for is
-// one 16-byte record (TileRec); one vector sc1 load per round fetches the records of all tiles in flight
-// (and a group leader's window), v_readlane moves what is needed into SGPRs.
+// one 16-byte record (TileRec), polled as two 8-byte words by two lanes (an aligned 8-byte word read by one lane
+// is one request: never a mix of two values); a leader's window of group granules rides in the same vector load.
 //
 // Offsets come from a two-level scan over the granules: the LAST tile of every 64-tile group is the
 // group's leader.  Its scout (LeaderDuty) reads the 64 bit counts of the group (one vector load),
 // publishes the group's aggregate, walks the group granules downwards (16 per round) to the nearest
 // inclusive prefix, publishes the group's inclusive prefix and then the global offset of EVERY tile of the
 // group (one 64-lane store into the records).  So a tile's offset costs its own scout one poll per round,
-// and the chain packed -> leader -> records is three hand-offs whatever the input size.
-// The scout also draws the workgroup's tiles (RingCtl).  It free-runs: it takes no part in the data waves'
-// barrier and hands results over through LDS.
+// and the chain published -> leader -> records is three hand-offs whatever the input size.
+// The scout also draws the workgroup's tiles from the ticket counters.  It free-runs and hands results over
+// through LDS.
+//
+// Tiles are handed out DYNAMICALLY: every tile a workgroup works on is drawn by its scout from one of
+// kTicketClasses atomic counters (draw k of class c is tile 64k + (c + k) % 64, so the classes interleave, the
+// group-leader role rotates over them and a workgroup never holds two tiles of one group).  A workgroup draws a
+// tile only when it is about to work on it, so (1) no tile ever waits for a workgroup that is not running: forward
+// progress does not depend on the grid being co-resident, and (2) a slow workgroup just draws fewer tiles instead of
+// setting everybody's pace.  Tile numbers are limited to 28 bits by the host (32-bit record offsets).
 // ------------------------------------------------------------------------------------------------
-static_assert(kMaxIn <= kMaxSlots, "the scout polls at most kMaxSlots records per round");
+constexpr int kMaxPoll = 6;        // records the scout polls per round (lanes 0..11, 8 bytes each)
+constexpr int kWindow  = 16;       // group granules a leader looks at per round (lanes 32..47, 8 bytes each)
+static_assert(kMaxPoll < kSlots, "a polled tile's slot must still belong to it");
+
+template <bool WINDOW>
+__device__ __forceinline__ uint64_t poll_round(const EncodeParams& p, uint32_t rec_off, const void* w, int lane)
+{
+    const char* src = (const char*)p.recs + rec_off;
+    if (WINDOW && lane >= 32) src = (const char*)w + (uint32_t)(lane - 32) * 8u;
+    uint64_t v = 0;
+    if (lane < 2 * kMaxPoll || (WINDOW && lane >= 32 && lane < 32 + kWindow)) v = ld_granule((const uint64_t*)src);
+    return v;
+}
+__device__ __forceinline__ uint64_t lane_value64(uint64_t v, uint32_t l)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l) << 32) |
+           (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+}
+
 struct LeaderDuty {
     bool     active = false, have_bits = false, win_done = false;
     uint32_t g = 0, n = 0;      // group, tiles in it
-    uint32_t A = 0;             // aggregate of the group (64 tiles x < 2^22 bits)
+    uint32_t A = 0;             // aggregate of the group (64 tiles x < 2^20 bits)
     uint64_t E = 0;             // exclusive prefix of the group, collected so far
     int32_t  j = 0;             // next group granule to look at, walking down; -1: start of the stream
     uint32_t excl_in = 0;       // per lane: bits of the group's tiles before tile 64g+lane
 };
 
-__device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& sm, RingCtl c, int lane)
+__device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& sm, int lane)
 {
-    bool     act[kMaxIn], done[kMaxIn];
-    uint32_t til[kMaxIn];               // tile a slot holds (tile n of the workgroup uses slot n % kMaxIn)
-#pragma unroll
-    for (int s = 0; s < kMaxIn; ++s) { act[s] = false; done[s] = false; til[s] = 0; }
-    uint32_t rec_off = (uint32_t)(lane & 3) * 4u;   // per lane: what poll_round() reads (record 0 until a slot is started)
+    // lanes 2q, 2q+1 poll the record of the tile in poll slot q (workgroup-local tile n uses slot n % kMaxPoll):
+    // byte offset from p.recs of the 8 bytes this lane reads (record 0 until a slot is started)
+    uint32_t rec_off = (uint32_t)(lane & 1) * 8u;
     uint32_t n_started = 0, n_done = 0; // tiles whose record is being polled / handed to the data waves
     uint32_t n_duty = 0;                // tiles already checked for the group-leader role
     LeaderDuty d;
@@ -964,18 +957,18 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
 
         // (0) the ticket drawn in the previous round has arrived
         if (tix_inflight) {
-            const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)tix_k);
+            const uint32_t k = uni(tix_k);
             tix_inflight = false;
             progress = true;
             if ((uint64_t)k * kTicketClasses >= (uint64_t)ntiles) {
                 n_final = n_tix;
-                if (lane == 0) __hip_atomic_store(&sm.n_final, n_final, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) __hip_atomic_store(&sm.n_final, n_final, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
                 const uint32_t t = k * (uint32_t)kTicketClasses + ((cls + k) % (uint32_t)kTicketClasses);
                 if (t < ntiles) {       // (a draw in the last, partial block may fall behind the end: draw again)
                     if (lane == 0) {
                         sm.tq[n_tix % kTq] = t;
-                        __hip_atomic_store(&sm.n_tickets, n_tix + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        lds_rel(&sm.n_tickets, n_tix + 1u);
                     }
                     ++n_tix;
                 }
@@ -987,7 +980,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
         uint32_t bv = kValid32;
         if (d.active && !d.have_bits && (uint32_t)lane < d.n)
             bv = __hip_atomic_load(&p.bits32[(uint64_t)d.g * kGroupTiles + (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t pv;                     // lanes 0-23: the records of the tiles in flight; lanes 32-63: the leader's window
+        uint64_t pv;                     // lanes 0-11: the records of the tiles in flight; lanes 32-47: the leader's window
         if (d.active && !d.win_done) {
             const int32_t c0 = d.j & ~(kWindow - 1);
             pv = poll_round<true>(p, rec_off, p.group_desc + c0, lane);
@@ -995,7 +988,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
 #pragma unroll
             for (int i = kWindow - 1; i >= 0; --i) {
                 if (!stop && c0 + i <= d.j) {
-                    const uint64_t v  = ((uint64_t)lane_value(pv, 33 + 2 * i) << 32) | (uint64_t)lane_value(pv, 32 + 2 * i);
+                    const uint64_t v  = lane_value64(pv, 32u + (uint32_t)i);
                     const uint32_t st = (uint32_t)(v >> 62);
                     if (st == 0u) stop = true;                            // not published yet: again next round
                     else {
@@ -1011,54 +1004,45 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             pv = poll_round<false>(p, rec_off, nullptr, lane);
         }
 
-        // draw the next tile once the data waves are within two tiles of the last one drawn; the atomic is issued
-        // BEHIND this round's polls (in-order return) and its value is used at the top of the next round
-        if (n_final == ~0u && !tix_inflight &&
-            n_tix - __hip_atomic_load(&sm.n_packed_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)HVLC_TICKETS_AHEAD) {
+        // draw the next tile while the fastest data wave is within kTixAhead tiles of the last one drawn; the atomic is
+        // issued BEHIND this round's polls (in-order return) and its value is used at the top of the next round
+        if (n_final == ~0u && !tix_inflight && n_tix < lds_rlx(&sm.n_load_max) + (uint32_t)kTixAhead &&
+            n_tix - n_duty < (uint32_t)(kTq - 1)) {                 // (a tile number stays queued until the duty scan has seen it)
             if (lane == 0)
                 tix_k = __hip_atomic_fetch_add(&p.tickets[cls * (uint32_t)kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             tix_inflight = true;
         }
 
-        // (2) the tiles in flight: resolved when the leader's offset and the predecessor's tail are both there
-        const uint64_t vm = __ballot((pv >> 31) != 0u);                 // valid bits of all polled dwords at once
+        // (2) the tiles in flight, in order: resolved when the leader's offset and the predecessor's tail are both there
+        {
+            const uint64_t vP = __ballot((pv >> 63) != 0ull);                     // even lanes: P's valid bit
+            const uint64_t vT = __ballot((((uint32_t)pv) >> 31) != 0u);           // odd lanes: the tail's valid bit
+            uint32_t nd = n_done;
+            bool go = true;
 #pragma unroll
-        for (int s = 0; s < kMaxIn; ++s) {
-            if (act[s] && !done[s] && (((vm >> (4 * s + 1)) & 3ull) == 3ull || HVLC_DBG(p, kDbgNoLookback))) {
-                uint64_t P  = ((uint64_t)lane_value(pv, 4 * s + 1) << 32) | (uint64_t)lane_value(pv, 4 * s);
-                uint32_t tl = lane_value(pv, 4 * s + 2);
-                if (HVLC_DBG(p, kDbgNoLookback)) { P = kValid | ((uint64_t)til[s] * 36400ull); tl = kValid32; }
-                {
-                    if (lane == 0) {
-                        sm.ts[s].prefix    = P & kValMask;
-                        sm.ts[s].pred_tail = tl & 0x7fffffffu;
-                        // the carry word of the packed tile (a tile on the general path owns no ring words: it takes
-                        // the carry from pred_tail)
-                        if (sm.ts[s].need != 0u) sm.ring[sm.ts[s].start] = tl & 0x7fffffffu;
-                    }
-                    TL(p, til[s], 4, lane == 0);
-                    done[s] = true;
-                    progress = true;
+            for (int i = 0; i < kMaxPoll; ++i) {
+                if (go && nd < n_started) {
+                    const uint32_t q = nd % (uint32_t)kMaxPoll;
+                    const bool ok = (((vP >> (2u * q)) & 1ull) != 0ull && ((vT >> (2u * q + 1u)) & 1ull) != 0ull) ||
+                                    HVLC_DBG(p, kDbgNoLookback);
+                    if (ok) {
+                        uint64_t P  = lane_value64(pv, 2u * q) & kValMask;
+                        uint32_t tl = (uint32_t)lane_value64(pv, 2u * q + 1u) & 0x7fffffffu;
+                        if (HVLC_DBG(p, kDbgNoLookback)) { P = (uint64_t)uni(sm.tq[nd % kTq]) * 36400ull; tl = 0u; }
+                        if (lane == 0) {
+                            sm.ts[nd % kSlots].prefix    = P;
+                            sm.ts[nd % kSlots].pred_tail = tl;
+                        }
+                        TL(p, uni(sm.tq[nd % kTq]), 4, lane == 0);
+                        ++nd;
+                    } else go = false;
                 }
             }
-        }
-        // hand the resolved tiles over in order
-        uint32_t nd = n_done;
-#pragma unroll
-        for (int k = 0; k < kMaxIn; ++k) {
-            const uint32_t sl = nd % kMaxIn;
-            bool dn = false;
-#pragma unroll
-            for (int s = 0; s < kMaxIn; ++s) if ((uint32_t)s == sl) dn = done[s] && act[s];
-            if (nd < n_started && dn) {
-#pragma unroll
-                for (int s = 0; s < kMaxIn; ++s) if ((uint32_t)s == sl) { done[s] = false; act[s] = false; }
-                ++nd;
+            if (nd != n_done) {
+                n_done = nd;
+                progress = true;
+                if (lane == 0) lds_rel(&sm.n_resolved, n_done);
             }
-        }
-        if (nd != n_done) {
-            n_done = nd;
-            if (lane == 0) __hip_atomic_store(&sm.n_resolved, n_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
 
         // (3) the leader's duty
@@ -1083,22 +1067,18 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             progress = true;
         }
 
-        // (4) newly packed tiles: start polling their records; the last tile of a group starts that group's duty
-        const uint32_t np = __hip_atomic_load(&sm.n_packed_pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (n_started < np && n_started - n_done < (uint32_t)kMaxIn) {
-            const uint32_t sl = n_started % kMaxIn;
-            const uint32_t t  = (uint32_t)__builtin_amdgcn_readfirstlane((int)sm.tq[n_started % kTq]);
-#pragma unroll
-            for (int s = 0; s < kMaxIn; ++s)
-                if ((uint32_t)s == sl) { act[s] = true; done[s] = false; til[s] = t; }
-            if ((uint32_t)(lane >> 2) == sl) rec_off = t * (uint32_t)sizeof(TileRec) + (uint32_t)(lane & 3) * 4u;
+        // (4) newly published tiles: start polling their records; the last tile of a group starts that group's duty
+        const uint32_t nb = lds_acq(&sm.n_bits_pub);
+        while (n_started < nb && n_started - n_done < (uint32_t)kMaxPoll) {
+            const uint32_t q = n_started % (uint32_t)kMaxPoll;
+            const uint32_t t = uni(sm.tq[n_started % kTq]);
+            if ((uint32_t)(lane >> 1) == q) rec_off = t * (uint32_t)sizeof(TileRec) + (uint32_t)(lane & 1) * 8u;
             TL(p, t, 1, lane == 0);
             ++n_started;
             progress = true;
         }
-        const uint32_t nb = __hip_atomic_load(&sm.n_bits_pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         while (!d.active && n_duty < nb && !HVLC_DBG(p, kDbgNoLookback)) {
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)sm.tq[n_duty % kTq]);
+            const uint32_t t = uni(sm.tq[n_duty % kTq]);
             ++n_duty;
             if ((t & (uint32_t)(kGroupTiles - 1)) == (uint32_t)(kGroupTiles - 1) || t == last_tile) {
                 d.active = true; d.have_bits = false;
@@ -1108,7 +1088,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             }
         }
 
-        if (__hip_atomic_load(&sm.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+        if (lds_rlx(&sm.abort_flag)) return;
         // watchdog: nothing moved for timeout_ticks -> give up (and make every other workgroup give up)
         if (progress) { rounds = 0; t_progress = 0; }
         else {
@@ -1127,16 +1107,16 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
     }
 }
 
-// The persistent, pipelined encoder.  A workgroup = 3 DATA waves + 1 SCOUT wave (one wave per SIMD).  It draws
-// tiles from the ticket counters and keeps up to kMaxIn of them packed in its LDS ring while the scout waits
-// for their global bit offsets, so HBM latency, the inter-workgroup hand-offs and the LDS bit packing of
-// several tiles overlap inside one workgroup, on top of the overlap between the workgroups of a CU.
+// The persistent, pipelined encoder.  A workgroup = 7 DATA waves + 1 SCOUT wave (two waves per SIMD whatever the
+// placement).  It draws tiles from the ticket counters; every data wave keeps several packed parts in its LDS ring
+// while the scout waits for their tiles' global bit offsets, so HBM latency, the inter-workgroup hand-offs and the
+// LDS bit packing of several tiles overlap inside one wave, on top of the overlap between the waves of a CU.
 #ifndef HVLC_WAVES_PER_EU
 #define HVLC_WAVES_PER_EU 6
 #endif
 // LDS is passed as dynamic shared memory (sizeof(Smem)) so that the register allocator honours the
 // waves-per-SIMD request below instead of the occupancy the static LDS size would imply: 80 VGPRs
-// = 6 waves per SIMD = six 4-wave workgroups per CU.
+// = 6 waves per SIMD = three 8-wave workgroups per CU.
 __global__ void __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(HVLC_WAVES_PER_EU, 8)))
 k_encode(EncodeParams p)
 {
@@ -1153,18 +1133,17 @@ k_encode(EncodeParams p)
         return;
     }
     if (tid < 256) sm.lut[lut_slot((uint32_t)tid)] = p.lut[tid];
-    if (tid < kDataThreads) zero_words(sm.ring, kRingWords / 4u, tid);
-    if (tid == 0) {
-        sm.abort_flag = 0u; sm.abort_snap = 0u; sm.n_resolved = 0u; sm.n_packed_pub = 0u; sm.n_res_snap = 0u; sm.bar = 0u;
-        sm.n_tickets = 0u; sm.n_final = ~0u; sm.n_tix_snap = 0u; sm.n_final_snap = ~0u; sm.n_bits_pub = 0u;
+    {   // everything behind the table starts as zero: rings, records, counters
+        uint4* z = reinterpret_cast<uint4*>(&sm.ring[0][0]);
+        const uint32_t nvec = (uint32_t)((sizeof(Smem) - sizeof(sm.lut)) / 16u);
+        for (uint32_t i = (uint32_t)tid; i < nvec; i += (uint32_t)kEncThreads) z[i] = make_uint4(0, 0, 0, 0);
     }
-    if (tid < kMaxIn) { sm.ts[tid].bits = 0u; sm.ts[tid].flags = 0u; sm.ts[tid].start = 0u; sm.ts[tid].need = 0u; }
-
-    RingCtl c;
     if (blockIdx.x >= (uint32_t)p.num_tiles) return;
     __syncthreads();                                  // the only workgroup-wide barrier: LDS initialised
-    if (wave == kDataWaves) encode_scout_wave(p, sm, c, lane);
-    else           encode_data_waves(p, sm, c, tid, lane, wave);
+    if (tid == 0) sm.n_final = ~0u;
+    __syncthreads();
+    if (wave == kDataWaves) encode_scout_wave(p, sm, lane);
+    else                    encode_data_wave(p, sm, lane, wave);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1231,6 +1210,14 @@ __global__ void __launch_bounds__(kThreads) k_segment_bits(const uint32_t* in, u
     }
 }
 
+// Reset for k_exclusive_scan: granules zeroed, status word exchanged (atomic RMW, as k_prepare does), result cleared.
+__global__ void __launch_bounds__(kThreads) k_scan_reset(uint4* granules, uint64_t granule_vecs, uint32_t* status, uint64_t* result)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < granule_vecs; i += (uint64_t)gridDim.x * kThreads)
+        granules[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { (void)atomicExch(&status[0], 0u); result[0] = 0ull; }
+}
+
 // Exclusive scan uint32 -> uint64, single launch, wavefront-hierarchical: 16 elements per lane
 // serially, DPP scan across the wave, wave totals through LDS, workgroup totals through the same
 // two-level look-back granules as the encoder (replaces scan.cu:67-231 + scanLargeArray_kernel.cu).
@@ -1263,8 +1250,8 @@ __global__ void __launch_bounds__(kThreads) k_exclusive_scan(const uint32_t* in,
         const uint64_t wavebase = wave == 0 ? 0ull : wave == 1 ? w0 : wave == 2 ? w0 + w1 : w0 + w1 + w2;
         if (tid == 0) st_granule(&p.tile_bits[tile], kValid | (T & kValMask));
         if (wave == 0) {
-            uint64_t P = 0; uint32_t unused = 0;
-            const bool ok = lookback<true>(p, tile, T, lane, LbRegs(), P, unused);
+            uint64_t P = 0;
+            const bool ok = lookback<true>(p, tile, T, lane, LbRegs(), P);
             if (lane == 0) { s_prefix = P; if (!ok) s_abort = 1u; }
         }
         __syncthreads();
@@ -1272,7 +1259,7 @@ __global__ void __launch_bounds__(kThreads) k_exclusive_scan(const uint32_t* in,
         uint64_t run = s_prefix + wavebase + (incl - sum);
 #pragma unroll
         for (int k = 0; k < 16; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
-        if (total && tile == p.num_tiles - 1 && tid == kThreads - 1) *total = run;
+        if (tile == p.num_tiles - 1 && tid == kThreads - 1) { p.result[0] = run; if (total) *total = run; }
     }
 }
 
@@ -1372,7 +1359,8 @@ __global__ void __launch_bounds__(kThreads) k_decode(const uint32_t* __restrict_
     if (threadIdx.x == 0) nlong = 0;
     __syncthreads();
     {
-        const uint32_t len = cl[threadIdx.x], c = cw[threadIdx.x];
+        const uint32_t len = cl[threadIdx.x];
+        const uint32_t c = len >= 1 && len <= 31u ? (cw[threadIdx.x] & ((1u << len) - 1u)) : 0u;   // an invalid table must not index out of range
         if (len >= 1 && len <= (uint32_t)kDecBits) {
             const uint32_t base = c << (kDecBits - len), n = 1u << (kDecBits - len);
             for (uint32_t i = 0; i < n; ++i) fast[base + i] = (uint16_t)((threadIdx.x << 8) | len);

@@ -32,8 +32,9 @@ EXPORTS = [
     "hvlc_finish", "gpu_vlc_encode", "hvlc_segment_bits", "hvlc_exclusive_scan", "hvlc_rebase_offsets",
     "hvlc_rebase_offsets_dev", "hvlc_profile_begin", "hvlc_profile_collect",
     "hvlc_gen_symbols", "hvlc_histogram", "hvlc_build_table", "hvlc_merge_shard", "hvlc_decode", "hvlc_get_launch_info", "hvlc_last_hip_error",
-    "hvlc_status_string", "hvlc_version",
+    "hvlc_status_string", "hvlc_version", "hvlc_test_hook",
 ]
+HOOK_STALL_TILE, HOOK_FORCE_GRID = 1, 2
 
 
 class HvlcError(RuntimeError):
@@ -90,6 +91,7 @@ def lib():
     L.hvlc_histogram.argtypes = [vp, vp, u64, vp, vp]
     L.hvlc_get_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.hvlc_last_hip_error.argtypes = [vp]
+    L.hvlc_test_hook.argtypes = [vp, i32, C.c_int64]
     L.hvlc_status_string.argtypes = [i32]
     L.hvlc_status_string.restype = C.c_char_p
     L.hvlc_version.restype = C.c_char_p
@@ -161,6 +163,10 @@ class Encoder:
         if check:
             _check(rc, "hvlc_finish")
         return int(bits.value), rc
+
+    def test_hook(self, which, value):
+        """Test hooks of include/hvlc.h (stall a tile / force the grid size); never used in production."""
+        _check(lib().hvlc_test_hook(self._ctx, int(which), int(value)), "hvlc_test_hook")
 
     def launch_info(self):
         g, b, c = C.c_int(0), C.c_int(0), C.c_int(0)

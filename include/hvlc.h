@@ -89,8 +89,10 @@ int hvlc_encode(hvlc_ctx* ctx,
                 uint64_t* d_out_offsets, uint64_t* d_total_bits,
                 void* stream);
 
-/* Wait for the last hvlc_encode on `stream`, return its total bit count and its
- * device-side status (HVLC_OK / _TABLE / _CAPACITY / _TIMEOUT). */
+/* Wait for the last hvlc_encode (or hvlc_exclusive_scan) of this context on `stream`,
+ * return its total (bits / sum) and its device-side status
+ * (HVLC_OK / _TABLE / _CAPACITY / _TIMEOUT).  After a _TIMEOUT the outputs of that call are
+ * incomplete and must not be used. */
 int hvlc_finish(hvlc_ctx* ctx, void* stream, uint64_t* total_bits);
 
 /*
@@ -114,7 +116,9 @@ int hvlc_segment_bits(hvlc_ctx* ctx, const uint32_t* d_in, uint64_t num_words,
 
 /* Exclusive prefix sum uint32[n] -> uint64[n] (+ optional total): replaces
  * preallocBlockSums + prescanArray + deallocBlockSums (main_test_cu.cu:160-168)
- * with a single-launch wavefront-hierarchical scan. */
+ * with a single-launch wavefront-hierarchical scan.  Asynchronous like hvlc_encode:
+ * a look-back that gives up (bounded wait) is reported by hvlc_finish as
+ * HVLC_ERR_TIMEOUT. */
 int hvlc_exclusive_scan(hvlc_ctx* ctx, const uint32_t* d_counts, uint64_t n,
                         uint64_t* d_offsets, uint64_t* d_total, void* stream);
 
@@ -175,6 +179,15 @@ int hvlc_merge_shard(hvlc_ctx* ctx, const uint32_t* d_src_bits, uint64_t nbits, 
 int hvlc_decode(hvlc_ctx* ctx, const uint32_t* d_bits, uint64_t total_bits, const uint64_t* d_offsets,
                 const uint32_t* d_codewords, const uint32_t* d_codewordlens, uint32_t* d_out_words,
                 uint64_t num_words, void* stream);
+
+/* TEST HOOKS (used by tests/ only; a production caller never calls this).  They live in the context, are
+ * set explicitly and cost the launch path nothing (no environment variables are read by hvlc_encode):
+ *   HVLC_HOOK_STALL_TILE  value = a tile number whose bit count is never published, so that every later tile
+ *                         waits until the bounded waits give up with HVLC_ERR_TIMEOUT; value < 0 = off
+ *   HVLC_HOOK_FORCE_GRID  value = number of workgroups to launch instead of what is resident (a grid that is
+ *                         not co-resident must still finish with the exact stream); 0 = off */
+enum { HVLC_HOOK_STALL_TILE = 1, HVLC_HOOK_FORCE_GRID = 2 };
+int hvlc_test_hook(hvlc_ctx* ctx, int which, int64_t value);
 
 /* Introspection: launch geometry chosen for this device (grid, blocks per CU,
  * CUs) and the last HIP error code seen by this context. */

@@ -299,9 +299,9 @@ def test_timeout_is_reported_not_a_hang(golden, monkeypatch):
     wait for ever: the bounded waits must end in HVLC_ERR_TIMEOUT within the configured bound, not in a hung
     GPU, and a normal encode on a fresh context works afterwards."""
     import time
-    monkeypatch.setenv("HVLC_TIMEOUT_MS", "200")
-    monkeypatch.setenv("HVLC_TEST_STALL_TILE", "1000")
+    monkeypatch.setenv("HVLC_TIMEOUT_MS", "200")          # read once, by hvlc_create
     e2 = hvlc.Encoder(0, 1 << 24)
+    e2.test_hook(hvlc.HOOK_STALL_TILE, 1000)
     x = np.tile(golden["period"], 256).view(np.uint32)          # 64 MiB = 5462 tiles
     d_in = _dev(x); d_tab = e2.table_to_device(golden["cw"], golden["cl"])
     out = torch.empty(hvlc.out_capacity_words(x.size, 21), dtype=torch.int32, device="cuda")
@@ -311,7 +311,11 @@ def test_timeout_is_reported_not_a_hang(golden, monkeypatch):
     dt = time.time() - t0
     assert rc == hvlc.ERR_TIMEOUT, rc
     assert dt < 5.0, dt
-    monkeypatch.delenv("HVLC_TEST_STALL_TILE")
+    # the same context, hook off: the next launch is clean (every polled word is re-initialised per call)
+    e2.test_hook(hvlc.HOOK_STALL_TILE, -1)
+    o2, _, bits2 = e2.encode(d_in, d_tab, max_len=21)
+    ref, rbits = O.encode(x, golden["cw"], golden["cl"])
+    assert bits2 == rbits and torch.equal(o2[: bits2 // 32 + 1].cpu(), torch.from_numpy(ref.view(np.int32)))
     e2.close()
     e3 = hvlc.Encoder(0, 1 << 24)
     o3, _, bits = e3.encode(d_in, d_tab, max_len=21)
@@ -339,7 +343,7 @@ def test_oversubscribed_grid_still_encodes(golden, monkeypatch, factor):
     the device holds) must still produce the exact stream: forward progress does not depend on residency."""
     e2 = hvlc.Encoder(0, 1 << 24)
     info = e2.launch_info()
-    monkeypatch.setenv("HVLC_TEST_FORCE_GRID", str(factor * info["compute_units"] * info["blocks_per_cu"]))
+    e2.test_hook(hvlc.HOOK_FORCE_GRID, factor * info["compute_units"] * info["blocks_per_cu"])
     x = np.tile(golden["period"], 512).view(np.uint32)          # 128 MiB = 10923 tiles
     d_tab = e2.table_to_device(golden["cw"], golden["cl"])
     o, offs, bits = e2.encode(_dev(x), d_tab, max_len=21)

@@ -12,7 +12,7 @@ tab = np.fromfile(os.path.join(ROOT, "tests", "golden", "g1_table.bin"), dtype=n
 cw, cl = tab[:256].copy(), tab[256:].copy()
 e = hvlc.Encoder(0, 1 << 25)
 info = e.launch_info()
-if factor: os.environ["HVLC_TEST_FORCE_GRID"] = str(factor * info["compute_units"] * info["blocks_per_cu"])
+if factor: e.test_hook(hvlc.HOOK_FORCE_GRID, factor * info["compute_units"] * info["blocks_per_cu"])
 x = np.tile(period, 512).view(np.uint32)
 d_tab = e.table_to_device(cw, cl)
 ref, rbits = O.encode(x, cw, cl)
