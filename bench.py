@@ -11,13 +11,23 @@ H~2.2 byte stream PER GPU (weak scaling; at N ranks the job is the 4N GiB stream
 SURVEY.md section 8(d), shard g drawing from index g*2^31, seed 0x5EED0005), encoded with
 the Huffman table of the job's global histogram.  A "step" is one whole pass of the hot
 path over the rank's shard: hvlc_encode (k_prepare + the fused k_encode) and, for N>1,
-the stitch: ONE RCCL all-gather of the per-shard bit totals + the device-side rebase of the
-segment offsets.  Inputs are resident in HBM before the timed region; nothing is skipped.
+the stitch (hvlc.stitch): ONE RCCL all-gather of the per-shard bit totals + the device-side
+rebase of the segment offsets.  Inputs are resident in HBM before the timed region; nothing
+is skipped.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel k_encode, timed live
-with HIP events on its launch stream (hvlc_profile_begin/_collect); `cpu_baseline` times
-the compiled reference encoder (oracle/_ref, kind "reference") or, if absent, the repo's C
-restatement (kind "port") on a bounded sample of the same stream, rank 0, N=1 only.
+Prints ONE JSON line (rank 0):
+  value / ms_per_step   K steps timed as a whole (barrier + synchronize on both sides, max over ranks);
+                        step_ms_median / step_ms_best from per-step events on the launch stream
+  roofline              dominant kernel k_encode, timed live with HIP events on its launch stream
+                        (hvlc_profile_begin/_collect): mean (-> achieved), median and best;
+                        measured_read_ceiling / measured_mix_ceiling: in the SAME process, a kernel that only
+                        streams the same input (and, for the mix, writes this workload's output volume):
+                        what the memory system gives this traffic mix with no encoding work at all
+  bit_exact             after the timed region the stream of the LAST timed step is compared word for word with
+                        the CPU encoder's stream of a prefix of the same input (main_test_cu.cu:170-171):
+                        the reference's cpu_vlc_encode (oracle/_ref) when built, else the repo's C restatement
+  cpu_baseline          the same CPU run, timed (rank 0, N=1 only): kind "reference" / "port", 1 thread, plus
+                        the port on all host threads
 """
 import argparse
 import json
@@ -40,15 +50,49 @@ WORKLOADS = {                    # name -> (distribution, default MiB per GPU, s
 }
 
 
+def host_cpu():
+    """(model name, physical cores, hardware threads) of the host, from /proc/cpuinfo."""
+    model, cores, phys, core = "unknown", set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+    except OSError:
+        pass
+    threads = os.cpu_count() or 1
+    return model, (len(cores) or threads), threads
+
+
+def compare_prefix(gpu_words, ref_words, nbits):
+    """Word-for-word comparison of the first nbits bits of two MSB-first uint32 streams."""
+    full = nbits // 32
+    if not np.array_equal(gpu_words[:full], ref_words[:full]):
+        return False
+    rem = nbits % 32
+    if rem:
+        mask = np.uint32((0xFFFFFFFF << (32 - rem)) & 0xFFFFFFFF)
+        return bool((gpu_words[full] & mask) == (ref_words[full] & mask))
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="H2.2-4GiB", choices=sorted(WORKLOADS))
     ap.add_argument("--size-mib", type=int, default=0, help="override the per-GPU shard size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
+    ap.add_argument("--no-probe", action="store_true", help="skip the measured read / mix ceilings")
     args = ap.parse_args()
 
     import torch
@@ -77,8 +121,9 @@ def main():
     enc = hvlc.Encoder(local_rank, n_words)
     # ---- synthetic shard, resident in HBM -----------------------------------------------------
     cdf = hvlc.cdf32_from_counts(dist_weights(dname, period))
-    d_in = enc.gen_symbols(n_bytes, seed, cdf, first_draw=rank * (n_bytes // 2))
+    d_in = enc.gen_symbols(n_bytes, seed, cdf, first_draw=hvlc.shard_first_draw(rank, n_bytes))
     hist = enc.histogram(d_in)
+    local_hist = hist.cpu().numpy().astype(np.uint64)
     if world > 1:
         dist.all_reduce(hist)                              # table of the WHOLE job's histogram
     hist_np = hist.cpu().numpy().astype(np.uint64)
@@ -91,12 +136,14 @@ def main():
     total = torch.zeros(1, dtype=torch.int64, device=dev)
     gathered = torch.zeros(world, dtype=torch.int64, device=dev)
 
+    def rebase(g, r):
+        enc.rebase_offsets_dev(offsets, g, r)
+
     def step():
         enc.encode_ptr(d_in.data_ptr(), n_words, d_table.data_ptr(), d_table.data_ptr() + 1024,
                        out.data_ptr(), out.numel(), offsets.data_ptr(), total.data_ptr())
-        if world > 1:                                      # the stitch: one 8-byte-per-rank exchange over xGMI
-            dist.all_gather_into_tensor(gathered, total)
-            enc.rebase_offsets_dev(offsets, gathered, rank)
+        # the stitch: one 8-byte-per-rank exchange over xGMI + the rebase of this rank's offsets
+        hvlc.stitch(total, gathered, rank, world, dist.all_gather_into_tensor if world > 1 else None, rebase)
 
     def fence():
         if world > 1:
@@ -108,17 +155,20 @@ def main():
     fence()
     bits, rc = enc.finish()
     assert rc == 0, hvlc.status_string(rc)
-    local_hist = enc.histogram(d_in).cpu().numpy().astype(np.uint64)
     assert bits == int((local_hist * cl).sum()), "bit total does not match histogram x lengths"
 
     enc.profile_begin(args.steps)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    ev[0].record()
+    for i in range(args.steps):
         step()
+        ev[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
     kernel_ms = enc.profile_collect(args.steps)
+    step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     bits2, rc = enc.finish()
     assert rc == 0 and bits2 == bits
 
@@ -129,58 +179,88 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * n_bytes / (dt / args.steps) / 1e9
 
+    # ---- bit-exactness of what was just timed, and the CPU baseline from the same CPU run -------
+    import oracle_lib as O
+    base_bits = int(gathered[:rank].sum().item()) if world > 1 else 0
+    smp = min((args.cpu_sample_mib if (world == 1 and not args.no_cpu_baseline) else 64) << 20, n_bytes)
+    smp -= smp % 1024                                       # whole segments
+    x = d_in[:smp].cpu().numpy().view(np.uint32)
+    use_ref = O.have_ref() and smp * max_len // 8 < (1 << 32)
+    t1 = time.perf_counter()
+    ref_words, osz = (O.ref_encode32 if use_ref else O.encode32)(x, cw, cl)
+    sec = time.perf_counter() - t1
+    seg_end = smp // 1024
+    pre_bits = (int(offsets[seg_end].item()) - base_bits) if seg_end < S else bits
+    got = out[: pre_bits // 32 + 1].cpu().numpy().view(np.uint32)
+    ok = (osz == (pre_bits + 7) // 8) and compare_prefix(got, ref_words, pre_bits)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    checked = torch.tensor([(pre_bits + 7) // 8], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist.all_reduce(checked)
+    bit_exact = bool(flag.item())
+    checked_bytes = int(checked.item())
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        model, pcores, threads = host_cpu()
+        _, sec_mt = O.encode_mt(x, cw, cl, threads)
+        cpu = {"value": round(smp / sec / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "reference" if use_ref else "port",
+               "sample": f"first {smp >> 20} MiB of the same stream, cpu_vlc_encode, 1 thread, {sec:.2f} s",
+               "cpu_model": model, "physical_cores": pcores, "hardware_threads": threads,
+               "all_threads": {"value": round(smp / sec_mt / 1e9, 3), "threads": threads, "kind": "port",
+                               "note": "independent contiguous chunks, one per hardware thread"}}
+
     # ---- roofline of the dominant kernel (rank-local) -----------------------------------------
     # algorithmic bytes per launch: read input once + write the stream once
     # + one uint64 offset per 1024-byte segment
     alg_bytes = n_bytes + (bits + 7) // 8 + 8 * S
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_src = None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch, if profiled
     if os.path.exists(tf):
         try:
             tj = json.load(open(tf))
             traffic = tj.get(args.workload if not args.size_mib else "", {}).get("hbm_bytes_per_launch")
+            traffic_src = "from profile: profiles/traffic.json (rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command, not measured in this run)"
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "k_encode", "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "k_encode", "kernel_ms": round(k_ms, 4),
+                "kernel_ms_median": round(float(np.median(kernel_ms)), 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                 "algorithmic_bytes": int(alg_bytes),
                 "input_only_frac": round(n_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-
-    # ---- CPU baseline on the host cores, same stream, bounded sample ---------------------------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle_lib as O
-        smp = min(args.cpu_sample_mib << 20, n_bytes)
-        x = d_in[:smp].cpu().numpy().view(np.uint32)
-        if O.have_ref():
-            kind = "reference"
-            t1 = time.perf_counter()
-            _, osz = O.ref_encode32(x, cw, cl)
-            sec = time.perf_counter() - t1
-        else:
-            kind = "port"
-            t1 = time.perf_counter()
-            _, osz = O.encode32(x, cw, cl)
-            sec = time.perf_counter() - t1
-        ncores = os.cpu_count() or 1
-        _, sec_mt = O.encode_mt(x, cw, cl, ncores)
-        cpu = {"value": round(smp / sec / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
-               "sample": f"first {smp >> 20} MiB of the same stream, cpu_vlc_encode, 1 thread, {sec:.2f} s",
-               "all_cores": {"value": round(smp / sec_mt / 1e9, 3), "cores": ncores, "kind": "port",
-                             "note": "independent contiguous chunks, one per host thread"}}
+    if not args.no_probe:
+        # what the memory system gives this traffic mix with no encoding work (clobbers `out`: verified above)
+        wpt = max(4, (int(round(1024.0 * bits / n_bytes / 32.0 * 4.0)) + 3) // 4 * 4)   # stream words per 4 KiB of input
+        rd_best, rd_med = enc.probe_bandwidth(d_in, None, 0, 0)
+        m1_best, _ = enc.probe_bandwidth(d_in, out, wpt, 1)
+        m2_best, _ = enc.probe_bandwidth(d_in, out, wpt, 2)
+        mix_best = min(m1_best, m2_best)
+        mix_total = n_bytes * (1.0 + wpt / 1024.0)
+        roofline.update({
+            "measured_read_ceiling": round(n_bytes / rd_best / 1e6, 1),
+            "measured_mix_ceiling": round(mix_total / mix_best / 1e6, 1),
+            "measured_mix_ceiling_input": round(n_bytes / mix_best / 1e6, 1),
+            "measured_ceiling_note": f"same process, GB/s: read-only dwordx4 nt stream of the input; read + {wpt * 4} B written per "
+                                     f"4 KiB read (best of dword / dwordx4 stores), total and input-only; no encoding work",
+            "frac_of_measured_mix": round(achieved / (mix_total / mix_best / 1e6), 4)})
 
     if rank == 0:
         info = enc.launch_info()
         line = {
             "metric": "encode GB/s (input bytes)", "value": round(value, 2), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 4), "step_ms_median": round(float(np.median(step_ms)), 4),
+            "step_ms_best": round(float(np.min(step_ms)), 4),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "bit_exact": bit_exact, "checked_bytes": checked_bytes,
             "config": {"workload": f"{mib} MiB/GPU synthetic {dname} byte stream (splitmix64 seed {seed:#x}), "
-                                   f"Huffman table of the job histogram (max len {max_len}), bit-exact vs cpu_vlc_encode",
+                                   f"Huffman table of the job histogram (max len {max_len}); stream prefix compared word for word "
+                                   f"with cpu_vlc_encode ({'reference' if use_ref else 'port'}) after the timed region",
                        "bytes_per_gpu": n_bytes, "segments_per_gpu": S, "out_bits_per_gpu": bits,
                        "bits_per_symbol": round(bits / n_bytes, 4),
                        "parallelism": f"shard{world}" if world > 1 else "single",
@@ -191,6 +271,8 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if not bit_exact:
+        sys.exit("bench.py: the GPU stream differs from the CPU encoder's stream")
 
 
 if __name__ == "__main__":

@@ -594,6 +594,47 @@ int hvlc_decode(hvlc_ctx* c, const uint32_t* d_bits, uint64_t total_bits, const 
     return HVLC_OK;
 }
 
+int hvlc_probe_bandwidth(hvlc_ctx* c, const void* d_in, uint64_t n_bytes, void* d_out, uint64_t out_bytes,
+                         uint32_t out_words_per_4k, int store_shape, int iters, float* ms_best, float* ms_median)
+{
+    if (!c || !d_in || !ms_best || n_bytes < 4096 || ((uintptr_t)d_in & 15u) || iters < 1 || iters > 64 ||
+        store_shape < 0 || store_shape > 2)
+        return HVLC_ERR_ARG;
+    const uint64_t tiles = n_bytes / 4096;
+    if (store_shape) {
+        if (!d_out || ((uintptr_t)d_out & 15u) || out_words_per_4k == 0 || (store_shape == 2 && (out_words_per_4k & 3u)) ||
+            tiles * (uint64_t)out_words_per_4k * 4u > out_bytes)
+            return HVLC_ERR_ARG;
+    }
+    HVLC_HIP(c, hipSetDevice(c->device));
+    hipEvent_t e0, e1;
+    HVLC_HIP(c, hipEventCreate(&e0));
+    HVLC_HIP(c, hipEventCreate(&e1));
+    const dim3 grid((unsigned)c->cus * 8u), block(kThreads);      // 32 waves per CU, two 4 KiB steps in flight each
+    uint32_t* sink = (uint32_t*)ws_result(c) + 4;                 // a workspace word nobody reads
+    std::vector<float> ms((size_t)iters);
+    int rc = HVLC_OK;
+    for (int i = 0; i < iters && rc == HVLC_OK; ++i) {
+        hipError_t e = hipEventRecord(e0, nullptr);
+        if (e == hipSuccess) {
+            if (store_shape == 0)      e = launch(k_probe_rw<0>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
+            else if (store_shape == 1) e = launch(k_probe_rw<1>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
+            else                       e = launch(k_probe_rw<2>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
+        }
+        if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms[(size_t)i], e0, e1);
+        if (e != hipSuccess) { c->last_hip = (int)e; rc = HVLC_ERR_HIP; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != HVLC_OK) return rc;
+    std::sort(ms.begin(), ms.end());
+    *ms_best = ms[0];
+    if (ms_median) *ms_median = ms[ms.size() / 2];
+    return HVLC_OK;
+}
+
 int hvlc_gen_symbols(hvlc_ctx* c, uint8_t* d_out, uint64_t n_bytes, uint64_t seed,
                      uint64_t first_draw, const uint32_t* d_cdf32, void* stream)
 {

@@ -196,12 +196,15 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t x)
 
 // Bounded wait: ~every 1024 polls look at the 100 MHz real-time counter and at the global
 // status word; give up (and make everybody else give up) after timeout_ticks.
+#ifndef HVLC_WAIT_SLEEP
+#define HVLC_WAIT_SLEEP 64       // x64 clocks per look of a WAITING wave at its LDS words (s_wakeup ends the sleep early)
+#endif
 struct Spin {
     uint64_t t0 = 0;
     uint32_t n  = 0;
     __device__ __forceinline__ bool wait(const EncodeParams& p)
     {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(HVLC_WAIT_SLEEP);
         if ((++n & 1023u) == 0u) {
             const uint64_t now = __builtin_amdgcn_s_memrealtime();
             const uint32_t st  = atomicOr(p.status, 0u);     // RMW: coherent with the other workgroups' atomicOr
@@ -256,6 +259,10 @@ __device__ __forceinline__ uint32_t extract_tail(const uint32_t* st, uint32_t e)
 // and serialise 8-way.  hash4() applies the permutation to the four symbols of a word at once.
 __device__ __forceinline__ uint32_t lut_slot(uint32_t s) { return s ^ (s >> 4); }
 __device__ __forceinline__ uint32_t hash4(uint32_t w) { return w ^ ((w >> 4) & 0x0f0f0f0fu); }
+// k_prepare decides per table whether the permutation is needed at all (EncodeParams::status[1]): where the
+// identity layout conflicts no more than the permuted one, the hot loop saves the two instructions per word.
+// Cold paths select at run time:
+__device__ __forceinline__ uint32_t hash4_if(uint32_t w, bool permuted) { return permuted ? hash4(w) : w; }
 
 // LDS byte offset (slot * 8) of byte B of the hashed word h in ONE VALU op: SDWA selects the byte,
 // the shift scales it to the 8-byte table entries.
@@ -279,50 +286,51 @@ __device__ __forceinline__ uint2 lut_at(const uint2* /*lut*/, uint32_t byte_off)
     const u32x2 e = *reinterpret_cast<lds_u32x2*>((uintptr_t)byte_off);
     return make_uint2(e.x, e.y);
 }
-#define HVLC_SYM(B)                                              \
-    {                                                            \
-        const uint2 e = lut_at(lut, slot_offset<B>(h));          \
-        acc = (acc << e.y) | e.x;                                \
-        tot += e.y;                                              \
-    }
-
-template <bool FULL>
-__device__ __forceinline__ void encode16(const uint4& v, int nvalid, const uint2* lut,
-                                         uint64_t& acc, uint32_t& tot)
+// One lane-row of a FULL tile: 16 lookups, a 16-step shift-or chain for the bits and the lengths summed three at a
+// time (v_add3_u32): 3.5 vector instructions per symbol, or 3 when the table needs no slot permutation (HASH false).
+template <bool HASH>
+__device__ __forceinline__ void encode16(const uint4& v, const uint2* lut, uint64_t& acc, uint32_t& tot)
 {
-    const uint32_t w[4] = { hash4(v.x), hash4(v.y), hash4(v.z), hash4(v.w) };
+    const uint32_t w[4] = { HASH ? hash4(v.x) : v.x, HASH ? hash4(v.y) : v.y, HASH ? hash4(v.z) : v.z, HASH ? hash4(v.w) : v.w };
     acc = 0; tot = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (!FULL && k >= nvalid) break;
         const uint32_t h = w[k];
-        HVLC_SYM(3) HVLC_SYM(2) HVLC_SYM(1) HVLC_SYM(0)
+        const uint2 e3 = lut_at(lut, slot_offset<3>(h));
+        const uint2 e2 = lut_at(lut, slot_offset<2>(h));
+        const uint2 e1 = lut_at(lut, slot_offset<1>(h));
+        const uint2 e0 = lut_at(lut, slot_offset<0>(h));
+        acc = (acc << e3.y) | e3.x;
+        acc = (acc << e2.y) | e2.x;
+        acc = (acc << e1.y) | e1.x;
+        acc = (acc << e0.y) | e0.x;
+        tot = (tot + e3.y) + (e2.y + e1.y + e0.y);
     }
 }
-#undef HVLC_SYM
 
-// The hot-path form: n <= 64 bits, n == 0 allowed, always three ORs (the third is usually zero) -- no
-// per-lane branches.  Needs two readable words behind the tile's last data word (the ring allocation has them).
-__device__ __forceinline__ void put_bits64_flat(uint32_t* st, uint32_t q, uint64_t acc, uint32_t n)
+// The hot-path form: the <=64 bits of `acc` (right-aligned, nothing above them) END at part-local bit e (exclusive);
+// always three ORs, no per-lane branches, no left-alignment: with r = e % 32 and W = e / 32 the words W-2, W-1, W
+// take hi >> r, {hi,lo} >> r and lo << (32-r).  Words in front of the string (down to two words in front of st[0])
+// only ever receive an OR with zero.
+__device__ __forceinline__ void put_bits64_end(uint32_t* st, uint32_t e, uint64_t acc)
 {
-    const uint64_t val = acc << ((64u - n) & 63u);                 // left-align the n bits (n == 0: acc == 0)
-    const uint32_t hi = (uint32_t)(val >> 32), lo = (uint32_t)val;
-    const uint32_t sh = q & 31u;
-    uint32_t* w = st + (q >> 5);
-    lds_or(w,     hi >> sh);
-    lds_or(w + 1, __builtin_amdgcn_alignbit(hi, lo, sh));          // sh == 0: lo
-    lds_or(w + 2, __builtin_amdgcn_alignbit(lo, 0u, sh));          // sh == 0: 0
+    const uint32_t hi = (uint32_t)(acc >> 32), lo = (uint32_t)acc;
+    const uint32_t r = e & 31u;
+    uint32_t* w = st + (e >> 5);
+    lds_or(w - 2, hi >> r);
+    lds_or(w - 1, __builtin_amdgcn_alignbit(hi, lo, r));           // r == 0: lo
+    lds_or(w,     __builtin_amdgcn_alignbit(lo, 0u, r));           // r == 0: 0
 }
 
 // A lane-row whose 16 codewords exceed 64 bits (lengths up to 31 allow 496): two symbols (<=62 bits)
 // per put_bits64.  Rare with real tables, so it runs as a divergent branch of the fast path.
 __device__ __forceinline__ void put_row_pairs(uint32_t* st, uint32_t q, const uint32_t (&wraw)[4], int nvalid,
-                                              const uint2* lut)
+                                              const uint2* lut, bool permuted)
 {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k >= nvalid) break;
-        const uint32_t w = hash4(wraw[k]);
+        const uint32_t w = hash4_if(wraw[k], permuted);
 #pragma unroll
         for (int b = 3; b >= 1; b -= 2) {
             const uint2 e0 = lut[(w >> (8 * b)) & 255u];
@@ -334,11 +342,11 @@ __device__ __forceinline__ void put_row_pairs(uint32_t* st, uint32_t q, const ui
 }
 
 // The same for a lane-row of a FULL tile read back from memory, as a rolled loop (cold code: keep it small).
-__device__ __forceinline__ void put_row_pairs_mem(uint32_t* st, uint32_t q, const uint32_t* src, const uint2* lut)
+__device__ __forceinline__ void put_row_pairs_mem(uint32_t* st, uint32_t q, const uint32_t* src, const uint2* lut, bool permuted)
 {
 #pragma unroll 1
     for (int k = 0; k < 8; ++k) {                             // pair k = bytes 3,2 (k even) or 1,0 (k odd) of word k/2
-        const uint32_t w  = hash4(src[k >> 1]);
+        const uint32_t w  = hash4_if(src[k >> 1], permuted);
         const uint32_t sh = (k & 1) ? 0u : 16u;
         const uint2 e0 = lut[(w >> (sh + 8u)) & 255u];
         const uint2 e1 = lut[(w >> sh) & 255u];
@@ -533,6 +541,14 @@ __device__ __forceinline__ void zero_words(uint32_t* base, uint32_t n_vec4, int 
 __device__ __forceinline__ uint32_t lds_acq(const uint32_t* p) { return uni(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 __device__ __forceinline__ uint32_t lds_rlx(const uint32_t* p) { return uni(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 __device__ __forceinline__ void lds_rel(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// Waiting data waves sleep (s_sleep) between looks at their LDS words; s_wakeup ends the sleep of every other wave of
+// the workgroup at once, so the scout's news (a tile number, a resolved tile) is seen without short polling intervals.
+__device__ __forceinline__ void wake_workgroup()
+{
+#ifndef HVLC_NO_WAKEUP
+    asm volatile("s_wakeup" ::: "memory");
+#endif
+}
 
 // One bounded waiting step of a data wave: false = the launch is being aborted (timeout somewhere).
 struct WaveWait {
@@ -643,7 +659,7 @@ __device__ __forceinline__ bool store_part(const EncodeParams& p, Smem& sm, uint
 // taken as one buffer, funnel-shifted and stored; the carry runs through the segments exactly as it runs through
 // parts.  Leaves the ring zeroed.
 __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint32_t* ring, uint32_t j, uint32_t tile,
-                                          int wave, int lane)
+                                          int wave, int lane, bool permuted)
 {
     const uint32_t slot = j % kSlots;
     uint64_t G = uni64(sm.ts[slot].prefix) + (uint64_t)uni(sm.wrec[slot][wave].base);
@@ -663,7 +679,7 @@ __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint3
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (k < n) {
-                const uint32_t h = hash4(w[k]);
+                const uint32_t h = hash4_if(w[k], permuted);
 #pragma unroll
                 for (int b = 3; b >= 0; --b) t += sm.lut[(h >> (8 * b)) & 255u].y;
             }
@@ -671,7 +687,7 @@ __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint3
         const uint32_t Tq = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (p.offsets && lane == 0 && seg < p.num_segs) p.offsets[seg] = G;
         if (lane == 0) ring[0] = carry;
-        put_row_pairs(ring + 1, incl - t, w, n, sm.lut);
+        put_row_pairs(ring + 1, incl - t, w, n, sm.lut, permuted);
         const uint32_t s = (uint32_t)G & 31u;
         const bool lastq = last_part && r == kRows - 1;
         uint32_t nown = (s + Tq) >> 5;
@@ -702,7 +718,7 @@ __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint3
 //      count), pack (three branch-free ds_or_b32 per lane-row), publish the part's tail
 // Waiting happens only for: a tile number (scout), ring space / a free slot (resolution of older tiles).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm, int lane, int wave)
+__device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm, int lane, int wave, bool permuted)
 {
     uint4 raw[kRows];
 #pragma unroll
@@ -759,10 +775,15 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
 
         // ---- 1: lookups, concatenation, scan (registers only)
         uint64_t acc[kRows];
-        uint32_t tot[kRows], excl[kRows], rowbase[kRows];
+        uint32_t tot[kRows], incl[kRows], rowbase[kRows];
         if (full) {
+            if (permuted) {
 #pragma unroll
-            for (int r = 0; r < kRows; ++r) encode16<true>(raw[r], 4, sm.lut, acc[r], tot[r]);
+                for (int r = 0; r < kRows; ++r) encode16<true>(raw[r], sm.lut, acc[r], tot[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) encode16<false>(raw[r], sm.lut, acc[r], tot[r]);
+            }
         } else {
             // the one tile the input ends in: bit counts only, the slow path packs it (cold code)
 #pragma unroll
@@ -774,7 +795,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < nv) {
-                        const uint32_t h = hash4(wd[k]);
+                        const uint32_t h = hash4_if(wd[k], permuted);
                         t += sm.lut[h >> 24].y + sm.lut[(h >> 16) & 255u].y + sm.lut[(h >> 8) & 255u].y + sm.lut[h & 255u].y;
                     }
                 tot[r] = t; acc[r] = 0;
@@ -783,10 +804,9 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         uint32_t T = 0;
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
-            const uint32_t incl = wave_incl_scan(tot[r]);
-            excl[r]    = incl - tot[r];
+            incl[r]    = wave_incl_scan(tot[r]);
             rowbase[r] = T;
-            T         += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            T         += (uint32_t)__builtin_amdgcn_readlane((int)incl[r], 63);
         }
 
         // ---- 2: the oldest part's stream stores, 3: the next tile's loads
@@ -845,25 +865,26 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         // ---- 4b: pack
         if (!slow) {
             uint32_t* const st = ring + start + 1;
-            uint32_t big = 0;                            // rows of this lane with more than 64 bits (rare)
+            if (!HVLC_DBG(p, kDbgNoPack)) {
+                const uint32_t longest = max(max(tot[0], tot[1]), max(tot[2], tot[3]));
+                if (!__any(longest > 64u)) {
 #pragma unroll
-            for (int r = 0; r < kRows; ++r) {
-                const uint32_t q = rowbase[r] + excl[r];
-                if (HVLC_DBG(p, kDbgNoPack)) { if (acc[r] == 0x123456789ull) st[q & 1023u] = tot[r]; continue; }
-                const bool fits = tot[r] <= 64u;
-                put_bits64_flat(st, q, fits ? acc[r] : 0ull, fits ? tot[r] : 0u);
-                big |= fits ? 0u : (1u << r);
-            }
-            if (__any(big != 0u)) {                      // cold: re-read such a lane-row (L2) and pack it pairwise
+                    for (int r = 0; r < kRows; ++r) put_bits64_end(st, rowbase[r] + incl[r], acc[r]);
+                } else {
+                    // cold: some lane-row holds more than 64 bits (rare with real tables): its `acc` is meaningless; re-read such
+                    // a row (L2) and pack it pairwise
 #pragma unroll
-                for (int r = 0; r < kRows; ++r) {
-                    if ((big >> r) & 1u) {
-                        const char* base = (const char*)p.in + (uint64_t)cur * (uint64_t)(kTileWords * 4);
-                        put_row_pairs_mem(st, rowbase[r] + excl[r],
-                                          (const uint32_t*)(base + (uint32_t)((wave * kRows + r) * 64 + lane) * 16u), sm.lut);
+                    for (int r = 0; r < kRows; ++r) put_bits64_end(st, rowbase[r] + incl[r], tot[r] <= 64u ? acc[r] : 0ull);
+#pragma unroll
+                    for (int r = 0; r < kRows; ++r) {
+                        if (tot[r] > 64u) {
+                            const char* base = (const char*)p.in + (uint64_t)cur * (uint64_t)(kTileWords * 4);
+                            put_row_pairs_mem(st, rowbase[r] + incl[r] - tot[r],
+                                              (const uint32_t*)(base + (uint32_t)((wave * kRows + r) * 64 + lane) * 16u), sm.lut, permuted);
+                        }
                     }
                 }
-            }
+            } else if (acc[0] + acc[1] + acc[2] + acc[3] == 0x123456789ull) st[incl[0] & 1023u] = tot[0];
             if (T >= 31u)                                // the part's last 31 bits are all its own: publish the tail now
                 publish_tail(p, sm, slot, wave, cur, extract_tail(st, T), lane);
             ++c.m_packed;
@@ -878,7 +899,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             }
             while (lds_acq(&sm.n_resolved) < c.m_packed)
                 if (!w.step(p, sm, lane)) return;
-            if (!slow_part(p, sm, ring, c.m_packed - 1u, cur, wave, lane)) return;
+            if (!slow_part(p, sm, ring, c.m_packed - 1u, cur, wave, lane, permuted)) return;
             ++c.m_stored;
             if (lane == 0) lds_rel(&sm.stored[wave], c.m_stored);
             c.head = 0;
@@ -963,6 +984,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             if ((uint64_t)k * kTicketClasses >= (uint64_t)ntiles) {
                 n_final = n_tix;
                 if (lane == 0) __hip_atomic_store(&sm.n_final, n_final, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                wake_workgroup();
             } else {
                 const uint32_t t = k * (uint32_t)kTicketClasses + ((cls + k) % (uint32_t)kTicketClasses);
                 if (t < ntiles) {       // (a draw in the last, partial block may fall behind the end: draw again)
@@ -970,6 +992,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
                         sm.tq[n_tix % kTq] = t;
                         lds_rel(&sm.n_tickets, n_tix + 1u);
                     }
+                    wake_workgroup();
                     ++n_tix;
                 }
             }
@@ -1042,6 +1065,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
                 n_done = nd;
                 progress = true;
                 if (lane == 0) lds_rel(&sm.n_resolved, n_done);
+                wake_workgroup();
             }
         }
 
@@ -1077,7 +1101,8 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             ++n_started;
             progress = true;
         }
-        while (!d.active && n_duty < nb && !HVLC_DBG(p, kDbgNoLookback)) {
+        if (HVLC_DBG(p, kDbgNoLookback)) n_duty = nb;
+        while (!d.active && n_duty < nb) {
             const uint32_t t = uni(sm.tq[n_duty % kTq]);
             ++n_duty;
             if ((t & (uint32_t)(kGroupTiles - 1)) == (uint32_t)(kGroupTiles - 1) || t == last_tile) {
@@ -1089,6 +1114,9 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
         }
 
         if (lds_rlx(&sm.abort_flag)) return;
+#ifdef HVLC_SCOUT_SLEEP
+        if (!progress) __builtin_amdgcn_s_sleep(HVLC_SCOUT_SLEEP);
+#endif
         // watchdog: nothing moved for timeout_ticks -> give up (and make every other workgroup give up)
         if (progress) { rounds = 0; t_progress = 0; }
         else {
@@ -1132,7 +1160,8 @@ k_encode(EncodeParams p)
         if (tid == 0) atomicOr(p.status, kFlagLayout);
         return;
     }
-    if (tid < 256) sm.lut[lut_slot((uint32_t)tid)] = p.lut[tid];
+    const bool permuted = uni(p.status[1]) != 0u;     // table layout chosen by k_prepare
+    if (tid < 256) sm.lut[permuted ? lut_slot((uint32_t)tid) : (uint32_t)tid] = p.lut[tid];
     {   // everything behind the table starts as zero: rings, records, counters
         uint4* z = reinterpret_cast<uint4*>(&sm.ring[0][0]);
         const uint32_t nvec = (uint32_t)((sizeof(Smem) - sizeof(sm.lut)) / 16u);
@@ -1143,7 +1172,7 @@ k_encode(EncodeParams p)
     if (tid == 0) sm.n_final = ~0u;
     __syncthreads();
     if (wave == kDataWaves) encode_scout_wave(p, sm, lane);
-    else                    encode_data_wave(p, sm, lane, wave);
+    else                    encode_data_wave(p, sm, lane, wave, permuted);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1165,8 +1194,23 @@ __global__ void __launch_bounds__(kThreads) k_prepare(const uint32_t* cw, const 
         if (len > 31u) { atomicOr(&bad, kFlagTable); len = 0u; }
         else if (len > 0u && (c >> len) != 0u) atomicOr(&bad, kFlagTable);   // cpuencode.cpp:35 precondition
         lut[threadIdx.x] = make_uint2(len ? (c & ((1u << len) - 1u)) : 0u, len);
+        // LDS layout of the table in k_encode: identity, or slot(s) = s ^ (s >> 4).  A ds_read_b64 serves a group of 32 lanes
+        // in one cycle unless DIFFERENT entries fall into the same pair of banks (slot mod 32).  Expected conflicting
+        // mass with symbol probabilities 2^-len: per bank pair, everything except its most probable entry.
+        __shared__ uint32_t mass[2][32], top[2][32];
+        if (threadIdx.x < 64) { (&mass[0][0])[threadIdx.x] = 0u; (&top[0][0])[threadIdx.x] = 0u; }
+        __syncthreads();
+        const uint32_t wgt = (len >= 1u && len <= 24u) ? (1u << (24u - len)) : 0u;
+        if (wgt) {
+            const uint32_t b0 = threadIdx.x & 31u, b1 = lut_slot(threadIdx.x) & 31u;
+            atomicAdd(&mass[0][b0], wgt); atomicMax(&top[0][b0], wgt);
+            atomicAdd(&mass[1][b1], wgt); atomicMax(&top[1][b1], wgt);
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
+            uint32_t c0 = 0, c1 = 0;
+            for (int b = 0; b < 32; ++b) { c0 += mass[0][b] - top[0][b]; c1 += mass[1][b] - top[1][b]; }
+            status[1] = (c0 <= c1 || c0 <= (1u << 24) / 32u) ? 0u : 1u;      // 1: permuted layout
             uint32_t f = bad;
             result[0] = 0ull;
             if (empty) {
@@ -1420,6 +1464,54 @@ __global__ void __launch_bounds__(kThreads) k_decode(const uint32_t* __restrict_
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bandwidth probe (hvlc_probe_bandwidth; SURVEY.md section 8(d): "a measured streaming-read ceiling from a trivial
+// dwordx4 read kernel in the same run").  No table, no bit work: what the memory system gives a kernel with the
+// encoder's ACCESS PATTERN -- every wave reads 4 KiB (4 x dwordx4 nt per lane) per step, two steps in flight --
+// and, for the mix, writes `wpt` words per 4 KiB read to a contiguous stream (the stream words of the step before,
+// so that the stores never wait for the loads just issued).
+//   STORE 0: read only   1: one dword per lane per store (the encoder's store shape)   2: dwordx4 per lane
+// ---------------------------------------------------------------------------------------------
+template <int STORE>
+__global__ void __launch_bounds__(kThreads) k_probe_rw(const uint4* __restrict__ in, uint64_t tiles4k, uint32_t* __restrict__ out,
+                                                       uint32_t wpt, uint32_t* sink)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const uint64_t nw = (uint64_t)gridDim.x * 4u, w0 = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const u32x4* src = (const u32x4*)in;
+    uint32_t acc = 0, prev = 0;
+    u32x4 a, b, c, d;
+    uint64_t t = w0;
+    if (t < tiles4k) {
+        const u32x4* q = src + t * 256u + lane;
+        a = __builtin_nontemporal_load(q); b = __builtin_nontemporal_load(q + 64); c = __builtin_nontemporal_load(q + 128); d = __builtin_nontemporal_load(q + 192);
+    }
+    for (; t < tiles4k; t += nw) {
+        // the stores of the PREVIOUS step first, then the next step's loads, then the wait for this step's data
+        if (STORE && t != w0) {
+            uint32_t* dst = out + (t - nw) * (uint64_t)wpt;
+            if (STORE == 1) { for (uint32_t k = lane; k < wpt; k += 64) dst[k] = prev; }
+            else            { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) *(u32x4*)(dst + k) = (u32x4){prev, prev, prev, prev}; }
+        }
+        u32x4 na = a, nb = b, nc = c, nd = d;
+        if (t + nw < tiles4k) {
+            const u32x4* q = src + (t + nw) * 256u + lane;
+            na = __builtin_nontemporal_load(q); nb = __builtin_nontemporal_load(q + 64); nc = __builtin_nontemporal_load(q + 128); nd = __builtin_nontemporal_load(q + 192);
+        }
+        prev = a.x ^ b.y ^ c.z ^ d.w;
+        acc += prev;
+        a = na; b = nb; c = nc; d = nd;
+    }
+    if (STORE && tiles4k > w0) {                       // the last step's words
+        const uint64_t tl = w0 + ((tiles4k - 1 - w0) / nw) * nw;
+        uint32_t* dst = out + tl * (uint64_t)wpt;
+        if (STORE == 1) { for (uint32_t k = lane; k < wpt; k += 64) dst[k] = prev; }
+        else            { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) *(u32x4*)(dst + k) = (u32x4){prev, prev, prev, prev}; }
+    }
+    if (acc == 0x12345678u) *sink = acc;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -32,7 +32,7 @@ EXPORTS = [
     "hvlc_finish", "gpu_vlc_encode", "hvlc_segment_bits", "hvlc_exclusive_scan", "hvlc_rebase_offsets",
     "hvlc_rebase_offsets_dev", "hvlc_profile_begin", "hvlc_profile_collect",
     "hvlc_gen_symbols", "hvlc_histogram", "hvlc_build_table", "hvlc_merge_shard", "hvlc_decode", "hvlc_get_launch_info", "hvlc_last_hip_error",
-    "hvlc_status_string", "hvlc_version", "hvlc_test_hook",
+    "hvlc_status_string", "hvlc_version", "hvlc_test_hook", "hvlc_probe_bandwidth",
 ]
 HOOK_STALL_TILE, HOOK_FORCE_GRID = 1, 2
 
@@ -92,6 +92,7 @@ def lib():
     L.hvlc_get_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.hvlc_last_hip_error.argtypes = [vp]
     L.hvlc_test_hook.argtypes = [vp, i32, C.c_int64]
+    L.hvlc_probe_bandwidth.argtypes = [vp, vp, u64, vp, u64, u32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.hvlc_status_string.argtypes = [i32]
     L.hvlc_status_string.restype = C.c_char_p
     L.hvlc_version.restype = C.c_char_p
@@ -244,6 +245,17 @@ class Encoder:
                                  C.c_uint64(int(num_words)), _stream_ptr(None)), "hvlc_decode")
         return out
 
+    def probe_bandwidth(self, d_in, d_out=None, out_words_per_4k=0, store_shape=0, iters=7):
+        """(best_ms, median_ms) of the streaming probe (hvlc_probe_bandwidth) over all of d_in."""
+        best, med = C.c_float(0), C.c_float(0)
+        n = d_in.numel() * d_in.element_size()
+        _check(lib().hvlc_probe_bandwidth(self._ctx, C.c_void_p(d_in.data_ptr()), n,
+                                          C.c_void_p(d_out.data_ptr() if d_out is not None else None),
+                                          (d_out.numel() * d_out.element_size()) if d_out is not None else 0,
+                                          int(out_words_per_4k), int(store_shape), int(iters), C.byref(best), C.byref(med)),
+               "hvlc_probe_bandwidth")
+        return float(best.value), float(med.value)
+
     def profile_begin(self, max_launches):
         _check(lib().hvlc_profile_begin(self._ctx, int(max_launches)), "hvlc_profile_begin")
 
@@ -299,6 +311,26 @@ def shard_bounds(total_words, world, rank):
     s0 = rank * per + min(rank, extra)
     s1 = s0 + per + (1 if rank < extra else 0)
     return min(s0 * SEGMENT_WORDS, total_words), min(s1 * SEGMENT_WORDS, total_words)
+
+
+def shard_first_draw(rank, shard_bytes):
+    """Draw index at which rank's shard of a synthetic job stream starts: the generator makes two symbols per
+    draw, so equal shards of `shard_bytes` bytes start shard_bytes/2 draws apart and the shards of all ranks,
+    concatenated, are the stream a single generation from draw 0 produces."""
+    assert int(shard_bytes) % 2 == 0
+    return int(rank) * (int(shard_bytes) // 2)
+
+
+def stitch(total, gathered, rank, world, all_gather, rebase):
+    """The multi-rank part of ONE step of the path, shared by bench.py and the tests:
+    one all-gather of the per-shard bit totals (8 bytes per rank), then the rebase of this rank's segment offsets
+    by the exclusive prefix of the totals.
+      total, gathered   int64 tensors of 1 and `world` elements (device tensors under RCCL, CPU tensors under gloo)
+      all_gather        e.g. torch.distributed.all_gather_into_tensor
+      rebase(gathered, rank)   adds sum(gathered[:rank]) to this rank's offsets (Encoder.rebase_offsets_dev)"""
+    if world > 1:
+        all_gather(gathered, total)
+        rebase(gathered, rank)
 
 
 def stitch_base(shard_total_bits, rank):

@@ -142,6 +142,15 @@ int hvlc_rebase_offsets_dev(hvlc_ctx* ctx, uint64_t* d_offsets, uint64_t n,
 int hvlc_profile_begin(hvlc_ctx* ctx, int max_launches);
 int hvlc_profile_collect(hvlc_ctx* ctx, float* ms, int* count);
 
+/* Measured memory ceilings for the roofline: times a kernel that does nothing but stream
+ * n_bytes from d_in (4 x dwordx4 non-temporal loads per lane per 4 KiB, the encoder's load shape) and, for
+ * store_shape != 0, write out_words_per_4k words per 4 KiB read to a contiguous stream in d_out (the encoder's
+ * traffic mix: 1024 * bits_per_symbol / 32 words per 4 KiB).  store_shape 0 = read only, 1 = one dword per lane
+ * per store instruction (the encoder's store shape), 2 = dwordx4 per lane (out_words_per_4k % 4 == 0).
+ * Synchronous on the default stream; runs `iters` launches and returns the best and the median duration in ms. */
+int hvlc_probe_bandwidth(hvlc_ctx* ctx, const void* d_in, uint64_t n_bytes, void* d_out, uint64_t out_bytes,
+                         uint32_t out_words_per_4k, int store_shape, int iters, float* ms_best, float* ms_median);
+
 /* Deterministic synthetic symbol stream on the device:
  * r = splitmix64(seed + first_draw + j), two symbols per draw through a 256-entry
  * 32-bit cumulative table d_cdf32.  n_bytes even, d_out 4-byte aligned. */

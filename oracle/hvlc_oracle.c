@@ -210,6 +210,74 @@ uint64_t oracle_vlc_encode_mt(const uint32_t* indata, uint64_t num_elements,
     return bits;
 }
 
+/* ---- whole-stream comparison in chunks, multi-threaded (checker for the 4 GiB configurations) ----------------- */
+typedef struct {
+    const uint32_t* in; uint64_t n; const uint32_t* cw; const uint32_t* cl;
+    const uint32_t* stream; uint64_t stream_words; const uint64_t* offs; uint64_t total_bits;
+    uint64_t chunk_segs; int tid, threads; uint64_t bad, first_bad;
+} cmp_job_t;
+
+static uint32_t stream_get32(const uint32_t* s, uint64_t nwords, uint64_t pos)
+{
+    const uint64_t w = pos >> 5; const uint32_t sh = (uint32_t)(pos & 31u);
+    const uint32_t hi = w < nwords ? s[w] : 0u, lo = w + 1 < nwords ? s[w + 1] : 0u;
+    return sh ? ((hi << sh) | (lo >> (32u - sh))) : hi;
+}
+
+static void* cmp_worker(void* p)
+{
+    cmp_job_t* j = (cmp_job_t*)p;
+    const uint64_t S = (j->n + 255u) / 256u;
+    const uint64_t chunk_words = j->chunk_segs * 256u;
+    uint32_t* buf   = (uint32_t*)malloc((size_t)(chunk_words * 4u * 31u / 32u + 4u) * sizeof(uint32_t));
+    uint32_t* cnt   = (uint32_t*)malloc((size_t)j->chunk_segs * sizeof(uint32_t));
+    uint64_t* loff  = (uint64_t*)malloc((size_t)j->chunk_segs * sizeof(uint64_t));
+    j->bad = 0; j->first_bad = ~(uint64_t)0;
+    for (uint64_t c = (uint64_t)j->tid; c * j->chunk_segs < S; c += (uint64_t)j->threads) {
+        const uint64_t seg0 = c * j->chunk_segs, seg1 = seg0 + j->chunk_segs < S ? seg0 + j->chunk_segs : S;
+        const uint64_t w0 = seg0 * 256u, w1 = seg1 * 256u < j->n ? seg1 * 256u : j->n;
+        const uint64_t bits = oracle_vlc_encode64(j->in + w0, w1 - w0, buf, j->cw, j->cl);
+        const uint64_t start = j->offs[seg0], end = seg1 < S ? j->offs[seg1] : j->total_bits;
+        int ok = (end >= start) && (end - start == bits);
+        if (ok) {
+            (void)oracle_segment_offsets(j->in + w0, w1 - w0, 256u, j->cl, cnt, loff);
+            for (uint64_t i = 0; ok && i < seg1 - seg0; ++i) ok = j->offs[seg0 + i] == start + loff[i];
+        }
+        const uint64_t full = bits >> 5;
+        for (uint64_t i = 0; ok && i < full; ++i) ok = stream_get32(j->stream, j->stream_words, start + 32u * i) == buf[i];
+        if (ok && (bits & 31u)) {
+            const uint32_t mask = ~0u << (32u - (uint32_t)(bits & 31u));
+            ok = ((stream_get32(j->stream, j->stream_words, start + 32u * full) ^ buf[full]) & mask) == 0u;
+        }
+        if (!ok) { j->bad++; if (seg0 < j->first_bad) j->first_bad = seg0; }
+    }
+    free(buf); free(cnt); free(loff);
+    return NULL;
+}
+
+uint64_t oracle_compare_stream_mt(const uint32_t* indata, uint64_t num_elements,
+                                  const uint32_t* codewords, const uint32_t* codewordlens,
+                                  const uint32_t* stream, uint64_t stream_words,
+                                  const uint64_t* seg_offsets, uint64_t total_bits,
+                                  uint64_t chunk_segments, int threads, uint64_t* first_bad_segment)
+{
+    if (threads < 1) threads = 1;
+    if (chunk_segments < 1) chunk_segments = 1;
+    cmp_job_t* jobs = (cmp_job_t*)calloc((size_t)threads, sizeof(cmp_job_t));
+    pthread_t* tids = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    for (int t = 0; t < threads; ++t)
+        jobs[t] = (cmp_job_t){ indata, num_elements, codewords, codewordlens, stream, stream_words, seg_offsets, total_bits,
+                               chunk_segments, t, threads, 0, ~(uint64_t)0 };
+    for (int t = 1; t < threads; ++t) pthread_create(&tids[t], NULL, cmp_worker, &jobs[t]);
+    cmp_worker(&jobs[0]);
+    for (int t = 1; t < threads; ++t) pthread_join(tids[t], NULL);
+    uint64_t bad = 0, first = ~(uint64_t)0;
+    for (int t = 0; t < threads; ++t) { bad += jobs[t].bad; if (jobs[t].first_bad < first) first = jobs[t].first_bad; }
+    if (first_bad_segment) *first_bad_segment = first;
+    free(jobs); free(tids);
+    return bad;
+}
+
 /* ---- bit-exact append (checker for hvlc_merge_shard) ------------------------------ */
 uint64_t oracle_bit_append(uint32_t* dst, uint64_t dst_bits, const uint32_t* src, uint64_t nbits)
 {

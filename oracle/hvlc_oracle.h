@@ -95,6 +95,19 @@ uint64_t oracle_vlc_encode_mt(const uint32_t* indata, uint64_t num_elements,
                               const uint32_t* codewords, const uint32_t* codewordlens,
                               int threads, double* seconds);
 
+/* Whole-stream checker for inputs too large for one sequential pass (the 4 GiB BASELINE configs): the input is
+ * cut into chunks of `chunk_segments` 256-word segments; every chunk is encoded on its own from bit 0
+ * (oracle_vlc_encode64 -- the encoding is concatenative, cpuencode.cpp:21-41 carries no state but the bit cursor)
+ * and compared, word for word, with the bits of `stream` that start at seg_offsets[first segment of the chunk];
+ * the chunk's bit count and the offsets of all its segments are compared too.  `threads` host threads take the
+ * chunks round robin.  Returns the number of chunks that differ (0 = identical); *first_bad_segment = first
+ * segment of the first such chunk. */
+uint64_t oracle_compare_stream_mt(const uint32_t* indata, uint64_t num_elements,
+                                  const uint32_t* codewords, const uint32_t* codewordlens,
+                                  const uint32_t* stream, uint64_t stream_words,
+                                  const uint64_t* seg_offsets, uint64_t total_bits,
+                                  uint64_t chunk_segments, int threads, uint64_t* first_bad_segment);
+
 #ifdef __cplusplus
 }
 #endif

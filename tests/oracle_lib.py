@@ -55,6 +55,9 @@ def _load():
     lib.oracle_vlc_encode_mt.argtypes = [_u32p, C.c_uint64, _u32p, C.c_uint64, _u32p, _u32p,
                                          C.c_int, C.POINTER(C.c_double)]
     lib.oracle_vlc_encode_mt.restype = C.c_uint64
+    lib.oracle_compare_stream_mt.argtypes = [_u32p, C.c_uint64, _u32p, _u32p, _u32p, C.c_uint64, _u64p, C.c_uint64,
+                                             C.c_uint64, C.c_int, _u64p]
+    lib.oracle_compare_stream_mt.restype = C.c_uint64
     return lib
 
 
@@ -168,6 +171,20 @@ def encode_mt(indata, codewords, codewordlens, threads):
     bits = lib().oracle_vlc_encode_mt(_ptr(x, _u32p), x.size, _ptr(scratch, _u32p), scratch.size,
                                       _ptr(cw, _u32p), _ptr(cl, _u32p), threads, C.byref(sec))
     return int(bits), float(sec.value)
+
+
+def compare_stream_mt(indata, codewords, codewordlens, stream, seg_offsets, total_bits, chunk_segments=1024, threads=None):
+    """Whole-stream check in chunks on all host threads: (number of differing chunks, first bad segment)."""
+    x = np.ascontiguousarray(indata, dtype=np.uint32)
+    st = np.ascontiguousarray(stream, dtype=np.uint32)
+    offs = np.ascontiguousarray(seg_offsets, dtype=np.uint64)
+    cw, cl = _tables(codewords, codewordlens)
+    assert offs.size == (x.size + 255) // 256
+    first = C.c_uint64(0)
+    bad = lib().oracle_compare_stream_mt(_ptr(x, _u32p), x.size, _ptr(cw, _u32p), _ptr(cl, _u32p), _ptr(st, _u32p), st.size,
+                                         _ptr(offs, _u64p), int(total_bits), int(chunk_segments),
+                                         int(threads or os.cpu_count() or 1), C.byref(first))
+    return int(bad), int(first.value)
 
 
 # ---------------------------------------------------------------------------

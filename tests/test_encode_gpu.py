@@ -9,7 +9,7 @@ import torch
 
 import hvlc
 import oracle_lib as O
-from util import extract_bits, random_table, synth_on_device
+from util import dist_weights, extract_bits, random_table, synth_on_device
 
 pytestmark = pytest.mark.gpu
 
@@ -434,6 +434,91 @@ def test_config_4GiB_properties(enc, golden, name):
     _check_windows(enc, d_in, out, offs, bits, cw, cl, hist, 24, np.random.default_rng(1))
     del out, offs, d_in
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", ["H4.0", "H1.0", "H2.2"])
+def test_config_4GiB_full_compare(enc, golden, name):
+    """configs[2], [3] and the north-star 4 GiB H~2.2 case, compared WORD FOR WORD with the CPU oracle: the input is
+    cut at segment multiples into chunks, every chunk is encoded by the oracle on a host thread and compared with
+    the GPU stream bits at the chunk's offset (and the offsets of all its segments with the oracle's), which is the
+    reference's own check (main_test_cu.cu:170-171, comparison_helpers.h:5-16) at a size one sequential
+    cpu_vlc_encode call cannot reach."""
+    n = 4 << 30
+    d_in, cw, cl, hist = synth_on_device(enc, name, n, golden["period"])
+    out, offs, bits = enc.encode(d_in, enc.table_to_device(cw, cl), max_len=int(cl.max()))
+    assert bits == int((hist * cl.astype(np.uint64)).sum())
+    x = d_in.cpu().numpy().view(np.uint32)
+    stream = out[: bits // 32 + 1].cpu().numpy().view(np.uint32)
+    o64 = offs.cpu().numpy().view(np.uint64)
+    del out, offs, d_in
+    torch.cuda.empty_cache()
+    bad, first = O.compare_stream_mt(x, cw, cl, stream, o64, bits, chunk_segments=2048)
+    assert bad == 0, f"{bad} chunks differ, first at segment {first}"
+    # the open word is zero padded; a stream ending on a word boundary is followed by a zero word (cpuencode.cpp:39)
+    assert int(stream[bits // 32]) & ((1 << (32 - bits % 32)) - 1) == 0
+    # the checker does catch a flipped bit and a shifted offset
+    stream[12345678] ^= 0x00010000
+    bad, first = O.compare_stream_mt(x, cw, cl, stream, o64, bits, chunk_segments=2048)
+    assert bad == 1 and o64[first] <= 12345678 * 32 < o64[first + 2048]
+    stream[12345678] ^= 0x00010000
+    o64[777 * 2048 + 5] += 1
+    bad, first = O.compare_stream_mt(x, cw, cl, stream, o64, bits, chunk_segments=2048)
+    assert bad == 1 and first == 777 * 2048
+
+
+def test_two_ranks_on_one_gpu_shared_stitch_code(golden):
+    """The code bench.py runs at N > 1, on the one GPU of the test box: two "ranks" = two contexts on two streams.
+    Each generates its shard of the job stream (hvlc.shard_first_draw), encodes it from local bit 0, then runs
+    hvlc.stitch (the all-gather is replaced by a device-side copy of both totals; the rebase is the product's
+    hvlc_rebase_offsets_dev), and the shards are merged (hvlc_merge_shard) -- offsets and merged stream must equal the
+    oracle's encoding of the whole job stream."""
+    world, shard_bytes = 2, 48 << 20
+    period = golden["period"]
+    cdf = hvlc.cdf32_from_counts(dist_weights("H2.2", period))
+    encs = [hvlc.Encoder(0, shard_bytes // 4) for _ in range(world)]
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    shards, hists = [], []
+    for r in range(world):
+        d = encs[r].gen_symbols(shard_bytes, 0x5EED0005, cdf, first_draw=hvlc.shard_first_draw(r, shard_bytes))
+        shards.append(d)
+        hists.append(encs[r].histogram(d).cpu().numpy().astype(np.uint64))
+    whole = O.gen_symbols(world * shard_bytes, 0x5EED0005, cdf)                 # ONE generation from draw 0
+    assert np.array_equal(np.concatenate([s.cpu().numpy() for s in shards]), whole)
+    cw, cl = hvlc.build_table(hists[0] + hists[1])                             # table of the job histogram
+    S = hvlc.num_segments(shard_bytes // 4)
+    outs, offs, totals = [], [], []
+    gathered = torch.zeros(world, dtype=torch.int64, device="cuda")
+    for r in range(world):
+        with torch.cuda.stream(streams[r]):
+            d_tab = encs[r].table_to_device(cw, cl)
+            o = torch.empty(hvlc.out_capacity_words(shard_bytes // 4, int(cl.max())), dtype=torch.int32, device="cuda")
+            f = torch.empty(S, dtype=torch.int64, device="cuda")
+            t = torch.zeros(1, dtype=torch.int64, device="cuda")
+            encs[r].encode_ptr(shards[r].data_ptr(), shard_bytes // 4, d_tab.data_ptr(), d_tab.data_ptr() + 1024,
+                               o.data_ptr(), o.numel(), f.data_ptr(), t.data_ptr())
+            outs.append(o); offs.append(f); totals.append(t)
+    torch.cuda.synchronize()
+
+    def fake_all_gather(g, t):           # what RCCL's all-gather leaves in `gathered` on every rank
+        g.copy_(torch.cat(totals))
+
+    for r in range(world):
+        hvlc.stitch(totals[r], gathered, r, world, fake_all_gather,
+                    lambda g, rr, r=r: encs[r].rebase_offsets_dev(offs[r], g, rr))
+    torch.cuda.synchronize()
+    x = whole.view(np.uint32)
+    ref, rbits = O.encode(x, cw, cl)
+    _, roffs, _ = O.segment_offsets(x, cl)
+    tot = [int(t.item()) for t in totals]
+    assert sum(tot) == rbits
+    assert np.array_equal(torch.cat(offs).cpu().numpy().view(np.uint64), roffs)
+    merged = torch.zeros(rbits // 32 + 1, dtype=torch.int32, device="cuda")
+    for r in range(world):
+        encs[r].merge_shard(outs[r], tot[r], merged, hvlc.stitch_base(tot, r))
+    torch.cuda.synchronize()
+    assert torch.equal(merged.cpu(), torch.from_numpy(ref.view(np.int32)))
+    for e in encs:
+        e.close()
 
 
 def test_general_path_large(enc):

@@ -1,7 +1,8 @@
-"""-m "not gpu": the N>1 path on CPU with gloo, world size 2.  The per-shard encoder
-here is the ORACLE (tests may use it); what is under test is the product's host logic for sharding and
-stitching -- hvlc.shard_bounds / hvlc.stitch_base and the single all-gather of one uint64 per rank that
-bench.py performs over RCCL -- against the single-stream oracle."""
+"""-m "not gpu": the N>1 path on CPU with gloo, world size 2.  The per-shard generator and
+encoder here are the ORACLE (tests may use it); what is under test is the product's multi-rank host code, the SAME
+functions bench.py runs at N > 1 -- hvlc.shard_first_draw and hvlc.stitch (one all-gather of one uint64 per rank +
+the rebase) -- against one generation and one encoding of the whole job stream.  tests/test_encode_gpu.py
+(test_two_ranks_on_one_gpu_shared_stitch_code) drives the same functions with the real kernels on one device."""
 import os
 import socket
 
@@ -22,34 +23,47 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n_words, q):
+def _worker(rank, world, port, shard_bytes, q):
+    """One rank of the job, running the product's own multi-rank host code on CPU tensors over gloo:
+    hvlc.shard_first_draw (which part of the synthetic job stream this rank generates -- what bench.py passes to
+    hvlc_gen_symbols) and hvlc.stitch (the all-gather of the totals + the rebase; bench.py passes
+    dist.all_gather_into_tensor over RCCL and hvlc_rebase_offsets_dev).  The ORACLE stands in for the GPU kernels
+    (generator, encoder) -- tests may use it."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from util import dist_weights
     g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    table = np.fromfile(os.path.join(g, "g1_table.bin"), dtype=np.uint32)
-    cw, cl = table[:256], table[256:]
     period = np.fromfile(os.path.join(g, "g1_period.bin"), dtype=np.uint8)
-    x = np.tile(period, 4).view(np.uint32)[:n_words]
-    w0, w1 = hvlc.shard_bounds(n_words, world, rank)
-    shard = x[w0:w1]
-    words, bits = O.encode(shard, cw, cl)                       # stands in for hvlc_encode on this rank's GPU
-    _, offs, _ = O.segment_offsets(shard, cl)
+    cdf = hvlc.cdf32_from_counts(dist_weights("H2.2", period))
+    shard = O.gen_symbols(shard_bytes, 0x5EED0005, cdf, first_draw=hvlc.shard_first_draw(rank, shard_bytes))
+    hist = torch.from_numpy(O.histogram(shard).astype(np.int64))
+    dist.all_reduce(hist)                                        # table of the WHOLE job's histogram, as bench.py does
+    cw, cl = hvlc.huffman_table(hist.numpy().astype(np.uint64))
+    x = shard.view(np.uint32)
+    words, bits = O.encode(x, cw, cl)                            # stands in for hvlc_encode on this rank's GPU
+    _, offs, _ = O.segment_offsets(x, cl)
+    offs = offs.copy()
     total = torch.tensor([bits], dtype=torch.int64)
-    gathered = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(gathered, total)                            # the ONE exchange of the path: 8 bytes per rank
-    totals = [int(t.item()) for t in gathered]
-    base = hvlc.stitch_base(totals, rank)
-    q.put((rank, w0, w1, base, bits, (offs + np.uint64(base)).tolist(), words.tolist()))
+    gathered = torch.zeros(world, dtype=torch.int64)
+
+    def rebase(gth, r):                                          # stands in for hvlc_rebase_offsets_dev
+        offs[:] += np.uint64(int(gth[:r].sum().item()))
+
+    hvlc.stitch(total, gathered, rank, world, dist.all_gather_into_tensor, rebase)   # the ONE exchange: 8 bytes per rank
+    totals = [int(t) for t in gathered.tolist()]
+    q.put((rank, totals, bits, offs.tolist(), words.tolist(), cw.tolist(), cl.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(n_words, world=2):
+def _run(shard_bytes, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_words, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shard_bytes, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))
@@ -59,25 +73,37 @@ def _run(n_words, world=2):
     return res
 
 
-def test_two_rank_stitch_matches_single_stream(golden):
-    n_words = 100_000 + 77                 # ragged: last segment partial, odd number of segments
-    res = _run(n_words)
-    x = np.tile(golden["period"], 4).view(np.uint32)[:n_words]
-    ref_words, ref_bits = O.encode(x, golden["cw"], golden["cl"])
-    _, ref_offs, _ = O.segment_offsets(x, golden["cl"])
-    # shards tile the input at segment multiples
-    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == n_words and res[0][2] % 256 == 0
+def test_two_rank_job_matches_single_stream(golden):
+    shard_bytes, world = 300 * 1024, 2
+    res = _run(shard_bytes, world)
+    from util import dist_weights, extract_bits
+    cdf = hvlc.cdf32_from_counts(dist_weights("H2.2", golden["period"]))
+    whole = O.gen_symbols(world * shard_bytes, 0x5EED0005, cdf)            # ONE generation from draw 0
+    cw, cl = np.array(res[0][5], dtype=np.uint32), np.array(res[0][6], dtype=np.uint32)
+    assert res[1][5] == res[0][5] and res[1][6] == res[0][6]               # same table on every rank
+    cw1, cl1 = hvlc.huffman_table(O.histogram(whole))
+    assert np.array_equal(cw, cw1) and np.array_equal(cl, cl1)             # ... and it is the whole job's table
+    x = whole.view(np.uint32)
+    ref_words, ref_bits = O.encode(x, cw, cl)
+    _, ref_offs, _ = O.segment_offsets(x, cl)
+    totals = res[0][1]
+    assert res[1][1] == totals and totals == [res[0][2], res[1][2]] and sum(totals) == ref_bits
     # stitched offsets are exactly the single-stream offsets
-    offs = np.array(res[0][5] + res[1][5], dtype=np.uint64)
+    offs = np.array(res[0][3] + res[1][3], dtype=np.uint64)
     assert np.array_equal(offs, ref_offs)
-    assert res[0][4] + res[1][4] == ref_bits and res[1][3] == res[0][4]
     # bit-concatenation of the shard streams is the single stream
-    from util import extract_bits
-    w0 = np.array(res[0][6], dtype=np.uint32)
-    w1 = np.array(res[1][6], dtype=np.uint32)
-    b0, b1 = res[0][4], res[1][4]
+    w0 = np.array(res[0][4], dtype=np.uint32)
+    w1 = np.array(res[1][4], dtype=np.uint32)
+    b0, b1 = totals
     assert np.array_equal(extract_bits(ref_words, 0, b0), extract_bits(w0, 0, b0))
     assert np.array_equal(extract_bits(ref_words, b0, b1), extract_bits(w1, 0, b1))
+
+
+def test_stitch_is_a_no_op_for_one_rank():
+    total = torch.tensor([5], dtype=torch.int64)
+    gathered = torch.zeros(1, dtype=torch.int64)
+    hvlc.stitch(total, gathered, 0, 1, None, lambda g, r: (_ for _ in ()).throw(AssertionError("no rebase at world 1")))
+    assert hvlc.shard_first_draw(0, 4096) == 0 and hvlc.shard_first_draw(3, 4096) == 3 * 2048
 
 
 def test_shard_bounds_properties():
