@@ -178,6 +178,7 @@ int pick_blocks_per_cu(hvlc_ctx* c, K kernel, int block_threads, size_t dyn_lds,
 
 #ifdef HVLC_EXPERIMENT
 uint64_t* g_dbg_tl = nullptr;      // tools/ only: per-tile timeline
+uint64_t* g_dbg_ws = nullptr;      // tools/ only: per-wave time accounting
 #endif
 std::mutex g_default_mu;
 hvlc_ctx*  g_default_ctx = nullptr;
@@ -303,6 +304,7 @@ int hvlc_encode(hvlc_ctx* c,
 #ifdef HVLC_EXPERIMENT
     p.dbg = (uint32_t)env_int("HVLC_DBG", 0);
     p.dbg_tl = g_dbg_tl;
+    p.dbg_ws = g_dbg_ws;
 #endif
 
     const Layout l = layout_for(tiles);
@@ -336,6 +338,7 @@ int hvlc_test_hook(hvlc_ctx* c, int which, int64_t value)
 
 #ifdef HVLC_EXPERIMENT
 int hvlc_debug_set_timeline(void* d_buf) { g_dbg_tl = (uint64_t*)d_buf; return 0; }
+int hvlc_debug_set_wave_stats(void* d_buf) { g_dbg_ws = (uint64_t*)d_buf; return 0; }
 #endif
 
 int hvlc_profile_begin(hvlc_ctx* c, int max_launches)

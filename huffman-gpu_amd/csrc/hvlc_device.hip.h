@@ -65,7 +65,10 @@ constexpr int      kTileWords   = kDataThreads * kRows * 4;   // 7168 words = 28
 constexpr int      kTileVec     = kDataThreads * kRows;    // uint4s per tile
 constexpr int      kSegWords    = 256;
 constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 28: wave w owns segments 4w..4w+3
-constexpr int      kGroupTiles  = 64;
+#ifndef HVLC_GROUP_TILES
+#define HVLC_GROUP_TILES 64
+#endif
+constexpr int      kGroupTiles  = HVLC_GROUP_TILES;       // <= 64 (one lane per tile in the leader's scan) and <= kTicketClasses
 constexpr int      kScanTile    = 4096;                    // elements per workgroup pass of k_exclusive_scan
 #ifndef HVLC_TICKET_CLASSES
 #define HVLC_TICKET_CLASSES 64
@@ -110,6 +113,7 @@ struct EncodeParams {
     uint32_t        stall_tile;      // TEST HOOK: this tile's bit count is never published (~0: none); see hvlc_api.hip
     uint32_t        dbg;             // ablation flags, honoured only in -DHVLC_EXPERIMENT builds (tools/)
     uint64_t*       dbg_tl;          // per-tile timeline [tiles][8] (100 MHz ticks), -DHVLC_EXPERIMENT builds only
+    uint64_t*       dbg_ws;          // per-wave time accounting [grid][8 waves][16] (shader clocks), -DHVLC_EXPERIMENT builds only
 };
 
 // Ablation switches for tools/ablate.py.  In the product build HVLC_DBG() is a compile-time false.
@@ -118,10 +122,30 @@ enum : uint32_t { kDbgNoLookback = 1u, kDbgNoStore = 2u, kDbgNoPack = 4u, kDbgNo
 #define HVLC_DBG(p, bit) (((p).dbg & (bit)) != 0u)
 #define TL(p, tile, k, cond) do { if ((p).dbg_tl && (cond)) (p).dbg_tl[(uint64_t)(tile) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define TLV(p, tile, k, v, cond) do { if ((p).dbg_tl && (cond)) (p).dbg_tl[(uint64_t)(tile) * 8 + (k)] = (v); } while (0)
+// per-wave time accounting of a data wave (tools/wave_stats.py): shader clocks per phase and per cause of waiting
+enum { kWsEncode = 0, kWsStore, kWsArrive, kWsPack, kWsWaitTicket, kWsWaitDrain, kWsWaitSlot, kWsWaitRing, kWsWaitSlow, kWsWaitTail,
+       kWsTotal, kWsTiles, kWsNWaits };
+struct WaveStats {
+    uint64_t t[16]; uint64_t last;
+    __device__ __forceinline__ void init() { for (int i = 0; i < 16; ++i) t[i] = 0; last = __builtin_amdgcn_s_memtime(); t[kWsTotal] = last; }
+    __device__ __forceinline__ void lap(int i) { const uint64_t now = __builtin_amdgcn_s_memtime(); t[i] += now - last; last = now; }
+    __device__ __forceinline__ void dump(uint64_t* buf, int wave) {
+        t[kWsTotal] = __builtin_amdgcn_s_memtime() - t[kWsTotal];
+        if (buf) for (int i = 0; i < 16; ++i) buf[((uint64_t)blockIdx.x * 8 + wave) * 16 + i] = t[i];
+    }
+};
+#define WS_DECL WaveStats ws; ws.init()
+#define WS_LAP(i) ws.lap(i)
+#define WS_COUNT(i) (ws.t[i] += 1)
+#define WS_DUMP(p, wave, lane) do { if ((lane) == 0) ws.dump((p).dbg_ws, wave); } while (0)
 #else
 #define TL(p, tile, k, cond)
 #define TLV(p, tile, k, v, cond)
 #define HVLC_DBG(p, bit) false
+#define WS_DECL
+#define WS_LAP(i)
+#define WS_COUNT(i)
+#define WS_DUMP(p, wave, lane)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -371,9 +395,9 @@ __device__ __forceinline__ void put_row_pairs_mem(uint32_t* st, uint32_t q, cons
 constexpr int      kSlots   = 8;
 constexpr int      kTq      = 16;                          // queue of drawn tile numbers: workgroup-local tile n at [n % kTq]
 #ifndef HVLC_TICKETS_AHEAD
-#define HVLC_TICKETS_AHEAD 1
+#define HVLC_TICKETS_AHEAD 2
 #endif
-constexpr int      kTixAhead = HVLC_TICKETS_AHEAD;         // tiles the scout draws ahead of the fastest data wave
+constexpr int      kTixAhead = HVLC_TICKETS_AHEAD;         // tiles the scout draws ahead of the workgroup's slowest data wave
 static_assert(kTq >= kSlots + kTixAhead + 2, "a tile number must stay in the queue until every wave has stored the tile");
 #ifndef HVLC_WAVE_RING_WORDS
 #define HVLC_WAVE_RING_WORDS 1752
@@ -407,7 +431,7 @@ struct alignas(16) Smem {
     uint32_t  n_final;                        // scout -> data: the workgroup's tile count once the tickets ran out, else ~0
     uint32_t  n_resolved;                     // scout -> data: tiles whose global offset is known (in order)
     uint32_t  n_bits_pub;                     // data -> scout: tiles whose bit count is published (in order; atomic max)
-    uint32_t  n_load_max;                     // data -> scout: tiles some data wave has started to load (atomic max)
+    uint32_t  pad0_;
     uint32_t  abort_flag;
     uint32_t  pad_[2];
 };
@@ -726,6 +750,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
     uint32_t* const ring = sm.ring[wave];
     WaveCtl c;
     uint32_t n_final = ~0u;
+    WS_DECL;
 
     // store the oldest packed part if its tile is resolved
     auto try_store = [&]() -> int {      // 1 stored, 0 nothing to store, -1 abort
@@ -743,7 +768,6 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         const uint32_t t = uni(sm.tq[c.m_loaded % kTq]);
         load_tile(p, t, t < p.num_full_tiles, wave, lane, raw);
         ++c.m_loaded;
-        if (lane == 0) (void)__hip_atomic_fetch_max(&sm.n_load_max, c.m_loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return true;
     };
 
@@ -759,6 +783,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
                 if (st < 0) return;
                 if (st == 0 && !w.step(p, sm, lane)) return;
             }
+            WS_LAP(kWsWaitTicket);
         }
         if (c.m_loaded == c.m_packed) {                                   // nothing left to encode: store what is packed and leave
             WaveWait w;
@@ -767,6 +792,8 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
                 if (st < 0) return;
                 if (st == 0 && !w.step(p, sm, lane)) return;
             }
+            WS_LAP(kWsWaitDrain);
+            WS_DUMP(p, wave, lane);
             return;
         }
         const uint32_t cur  = uni(sm.tq[c.m_packed % kTq]);
@@ -809,9 +836,11 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             T         += (uint32_t)__builtin_amdgcn_readlane((int)incl[r], 63);
         }
 
+        WS_LAP(kWsEncode);
         // ---- 2: the oldest part's stream stores, 3: the next tile's loads
         if (try_store() < 0) return;
         (void)try_load();
+        WS_LAP(kWsStore);
 
         // ---- 4: slot, record, arrival, ring words
         if (c.m_packed >= (uint32_t)kSlots) {                 // the slot's previous tile must be stored by every wave
@@ -825,6 +854,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
                 if (st == 0 && !w.step(p, sm, lane)) return;
             }
         }
+        WS_LAP(kWsWaitSlot);
         const uint32_t need = (((T + 31u) >> 5) + 3u + 3u) & ~3u;    // carry word + data + the two words behind the data that pack / store touch
         const bool slow = !full || need > kWaveRing;
         if (lane == 0) {
@@ -850,6 +880,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             }
             TL(p, cur, 0, lane == 0);
         }
+        WS_LAP(kWsArrive);
         uint32_t start = 0;
         if (!slow) {
             WaveWait w;
@@ -860,6 +891,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             }
             c.head = start + need;
         }
+        WS_LAP(kWsWaitRing);
         if (lane == 0) *reinterpret_cast<uint2*>(&sm.wrec[slot][wave].start) = make_uint2(start, slow ? 0u : need);   // (read by this wave only)
 
         // ---- 4b: pack
@@ -888,6 +920,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             if (T >= 31u)                                // the part's last 31 bits are all its own: publish the tail now
                 publish_tail(p, sm, slot, wave, cur, extract_tail(st, T), lane);
             ++c.m_packed;
+            WS_LAP(kWsPack); WS_COUNT(kWsTiles);
         } else {
             // slow path: drain the ring, wait for this tile's offset, store the part directly
             ++c.m_packed;
@@ -903,6 +936,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             ++c.m_stored;
             if (lane == 0) lds_rel(&sm.stored[wave], c.m_stored);
             c.head = 0;
+            WS_LAP(kWsWaitSlow); WS_COUNT(kWsTiles);
         }
     }
 }
@@ -1027,9 +1061,12 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             pv = poll_round<false>(p, rec_off, nullptr, lane);
         }
 
-        // draw the next tile while the fastest data wave is within kTixAhead tiles of the last one drawn; the atomic is
-        // issued BEHIND this round's polls (in-order return) and its value is used at the top of the next round
-        if (n_final == ~0u && !tix_inflight && n_tix < lds_rlx(&sm.n_load_max) + (uint32_t)kTixAhead &&
+        // draw the next tile while the workgroup's SLOWEST data wave (a tile is published when its last wave has arrived)
+        // is within kTixAhead tiles of the last one drawn: a wave that ran further ahead would only fill its ring with
+        // parts that cannot be resolved before the slowest wave has arrived at their tiles, and the tiles of a group,
+        // drawn within a microsecond of each other, would be published over many iterations.  The atomic is issued
+        // BEHIND this round's polls (in-order return) and its value is used at the top of the next round
+        if (n_final == ~0u && !tix_inflight && n_tix < lds_rlx(&sm.n_bits_pub) + (uint32_t)kTixAhead &&
             n_tix - n_duty < (uint32_t)(kTq - 1)) {                 // (a tile number stays queued until the duty scan has seen it)
             if (lane == 0)
                 tix_k = __hip_atomic_fetch_add(&p.tickets[cls * (uint32_t)kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
