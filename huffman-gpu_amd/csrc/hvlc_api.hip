@@ -462,6 +462,7 @@ int hvlc_exclusive_scan(hvlc_ctx* c, const uint32_t* d_counts, uint64_t n,
     EncodeParams p;
     memset(&p, 0, sizeof(p));
     p.num_tiles = tiles;
+    p.stall_tile = c->hook_stall_tile;                        // ~0 unless a test set it (hvlc_test_hook)
     fill_granule_ptrs(c, tiles, p, true);
     const Layout l = layout_for(tiles);
     // granules zeroed and the status word reset by a kernel: the status word is only ever touched with atomic
@@ -504,12 +505,16 @@ int hvlc_rebase_offsets_dev(hvlc_ctx* c, uint64_t* d_offsets, uint64_t n,
 
 // SURVEY.md section 8(f) #2 -- the table for a byte histogram, on the host (the reference builds its table on the
 // host too: huffTree.h:55-94 + load_data.h:40-47).  Huffman code lengths by the textbook two-smallest merge
-// (ties: the older node first, so the result is deterministic), lengths above max_len repaired by flattening
-// the deepest leaves and lengthening the cheapest symbols until the Kraft sum is <= 1, then CANONICAL codewords
-// (sorted by length, then symbol), right-aligned -- the table format hvlc_encode takes.
+// (ties: the older node first, so the result is deterministic); if that tree is deeper than max_len, the OPTIMAL
+// length-limited lengths by package-merge instead; then CANONICAL codewords (sorted by length, then symbol),
+// right-aligned -- the table format hvlc_encode takes.
 int hvlc_build_table(const uint64_t* hist, uint32_t max_len, uint32_t* codewords, uint32_t* codewordlens)
 {
     if (!hist || !codewords || !codewordlens || max_len < 8 || max_len > 31) return HVLC_ERR_ARG;
+    {   // the sums of the tree nodes must fit 64 bits
+        uint64_t total = 0;
+        for (int s = 0; s < 256; ++s) { if (hist[s] > ~total) return HVLC_ERR_ARG; total += hist[s]; }
+    }
     uint32_t lens[256] = {0};
     struct Node { uint64_t w; uint32_t order; int left, right; };
     std::vector<Node> nodes;
@@ -540,21 +545,37 @@ int hvlc_build_table(const uint64_t* hist, uint32_t max_len, uint32_t* codewords
     uint32_t mx = 0;
     for (int s = 0; s < 256; ++s) if (lens[s] > mx) mx = lens[s];
     if (mx > max_len) {
-        std::vector<int> ord;
-        for (int s = 0; s < 256; ++s) if (lens[s]) ord.push_back(s);
-        std::sort(ord.begin(), ord.end(), [&](int x, int y) {
-            if (lens[x] != lens[y]) return lens[x] > lens[y];
-            if (hist[x] != hist[y]) return hist[x] < hist[y];
-            return x < y; });
-        for (int s : ord) if (lens[s] > max_len) lens[s] = max_len;
-        long double kraft = 0;
-        for (int s : ord) kraft += ldexpl(1.0L, -(int)lens[s]);
-        size_t i = ord.size() - 1;
-        while (kraft > 1.0L + 1e-18L) {                                   // lengthen the cheapest symbols that can still grow
-            const int s = ord[i];
-            if (lens[s] < max_len) { kraft -= ldexpl(1.0L, -(int)(lens[s] + 1)); lens[s] += 1; }
-            i = i > 0 ? i - 1 : ord.size() - 1;
+        // The Huffman tree is deeper than max_len: OPTIMAL length-limited lengths by package-merge (Larmore & Hirschberg).
+        // Leaves ascending by (count, symbol); max_len - 1 rounds of "pair up the previous list into packages, merge
+        // them with the leaves" (leaf first on equal weight); a symbol's length = the number of the first 2n-2 items of
+        // the last list it occurs in.  Weights are 128-bit (a package may hold a leaf up to max_len times).
+        typedef unsigned __int128 u128;
+        struct Item { u128 w; std::vector<uint8_t> cnt; };
+        std::vector<std::pair<uint64_t, int>> leaves;
+        for (int s = 0; s < 256; ++s) if (hist[s]) leaves.push_back({hist[s], s});
+        std::sort(leaves.begin(), leaves.end());
+        const size_t n = leaves.size();                                   // >= 2 here; 2^max_len >= 256 >= n
+        std::vector<Item> leaf_items(n);
+        for (size_t i = 0; i < n; ++i) { leaf_items[i].w = leaves[i].first; leaf_items[i].cnt.assign(n, 0); leaf_items[i].cnt[i] = 1; }
+        std::vector<Item> prev = leaf_items;
+        for (uint32_t round = 1; round < max_len; ++round) {
+            std::vector<Item> pk;
+            for (size_t i = 0; i + 1 < prev.size(); i += 2) {
+                Item it; it.w = prev[i].w + prev[i + 1].w; it.cnt = prev[i].cnt;
+                for (size_t k = 0; k < n; ++k) it.cnt[k] = (uint8_t)(it.cnt[k] + prev[i + 1].cnt[k]);
+                pk.push_back(std::move(it));
+            }
+            std::vector<Item> next;
+            size_t a = 0, b = 0;
+            while (a < n || b < pk.size()) {
+                if (b >= pk.size() || (a < n && leaf_items[a].w <= pk[b].w)) next.push_back(leaf_items[a++]);
+                else next.push_back(std::move(pk[b++]));
+            }
+            prev.swap(next);
         }
+        for (int s = 0; s < 256; ++s) lens[s] = 0;
+        for (size_t i = 0; i < 2 * n - 2 && i < prev.size(); ++i)
+            for (size_t k = 0; k < n; ++k) lens[leaves[k].second] += prev[i].cnt[k];
     }
     std::vector<std::pair<uint32_t, int>> bylen;
     for (int s = 0; s < 256; ++s) { codewords[s] = 0; codewordlens[s] = lens[s]; if (lens[s]) bylen.push_back({lens[s], s}); }

@@ -1208,6 +1208,12 @@ k_encode(EncodeParams p)
     __syncthreads();                                  // the only workgroup-wide barrier: LDS initialised
     if (tid == 0) sm.n_final = ~0u;
     __syncthreads();
+#ifdef HVLC_PRIO_YOUNG
+    if (wave >= 4 && wave < kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_YOUNG);
+#endif
+#ifdef HVLC_PRIO_SCOUT
+    if (wave == kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_SCOUT);
+#endif
     if (wave == kDataWaves) encode_scout_wave(p, sm, lane);
     else                    encode_data_wave(p, sm, lane, wave, permuted);
 }
@@ -1329,7 +1335,7 @@ __global__ void __launch_bounds__(kThreads) k_exclusive_scan(const uint32_t* in,
         const uint64_t w0 = wtot[0], w1 = wtot[1], w2 = wtot[2], w3 = wtot[3];
         const uint64_t T = w0 + w1 + w2 + w3;
         const uint64_t wavebase = wave == 0 ? 0ull : wave == 1 ? w0 : wave == 2 ? w0 + w1 : w0 + w1 + w2;
-        if (tid == 0) st_granule(&p.tile_bits[tile], kValid | (T & kValMask));
+        if (tid == 0 && tile != (uint64_t)p.stall_tile) st_granule(&p.tile_bits[tile], kValid | (T & kValMask));   // (stall_tile: test hook)
         if (wave == 0) {
             uint64_t P = 0;
             const bool ok = lookback<true>(p, tile, T, lane, LbRegs(), P);

@@ -343,9 +343,8 @@ def stitch_base(shard_total_bits, rank):
 # ------------------------------------------------------------------------------------------
 def huffman_lengths(counts, max_len=MAX_CODE_LEN):
     """Code lengths of a Huffman code for 256 symbol counts (0 = absent symbol -> length 0,
-    as load_data.h leaves unseen symbols).  Lengths above max_len are repaired by the usual
-    Kraft-sum heuristic (flatten the deepest leaves), which is only reached for extremely
-    skewed inputs."""
+    as load_data.h leaves unseen symbols).  If the Huffman tree is deeper than max_len (extremely
+    skewed inputs only) the optimal length-limited code is built by package-merge instead."""
     counts = [int(c) for c in counts]
     live = [(c, s) for s, c in enumerate(counts) if c > 0]
     lens = [0] * 256
@@ -365,17 +364,27 @@ def huffman_lengths(counts, max_len=MAX_CODE_LEN):
         heapq.heappush(heap, (c0 + c1, tie, m0 + m1))
         tie += 1
     if max(lens) > max_len:
-        order = sorted((s for s in range(256) if lens[s]), key=lambda s: (-lens[s], counts[s]))
-        for s in order:
-            lens[s] = min(lens[s], max_len)
-        kraft = sum(2.0 ** -lens[s] for s in order)
-        i = len(order) - 1
-        while kraft > 1.0 + 1e-12:          # lengthen the shortest codes that can still grow
-            s = order[i]
-            if lens[s] < max_len:
-                kraft -= 2.0 ** -(lens[s] + 1)
-                lens[s] += 1
-            i = i - 1 if i > 0 else len(order) - 1
+        # the Huffman tree is deeper than max_len: optimal length-limited lengths by package-merge (the same
+        # algorithm, item order and tie rule as hvlc_build_table in csrc/hvlc_api.hip)
+        leaves = sorted((c, s) for s, c in enumerate(counts) if c > 0)
+        n = len(leaves)
+        leaf_items = [(c, np.eye(1, n, i, dtype=np.int64)[0]) for i, (c, _) in enumerate(leaves)]
+        prev = list(leaf_items)
+        for _ in range(1, max_len):
+            pk = [(prev[i][0] + prev[i + 1][0], prev[i][1] + prev[i + 1][1]) for i in range(0, len(prev) - 1, 2)]
+            nxt, a, b = [], 0, 0
+            while a < n or b < len(pk):
+                if b >= len(pk) or (a < n and leaf_items[a][0] <= pk[b][0]):
+                    nxt.append(leaf_items[a]); a += 1
+                else:
+                    nxt.append(pk[b]); b += 1
+            prev = nxt
+        tot = np.zeros(n, dtype=np.int64)
+        for w, cnt in prev[: 2 * n - 2]:
+            tot += cnt
+        lens = [0] * 256
+        for i, (_, s) in enumerate(leaves):
+            lens[s] = int(tot[i])
     return np.array(lens, dtype=np.uint32)
 
 

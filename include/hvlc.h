@@ -165,9 +165,11 @@ int hvlc_histogram(hvlc_ctx* ctx, const uint8_t* d_data, uint64_t n_bytes,
 
 /* SURVEY.md section 8(f) #2 -- code table for a byte histogram (HOST function, no device needed; hvlc_histogram
  * produces the histogram on the device).  Replaces the reference's host-side table construction (huffTree.h:55-94,
- * load_data.h:40-47): Huffman code lengths (symbols with count 0 get length 0 = emit nothing), limited to max_len
- * (8..31) bits, canonical codewords right-aligned in `length` bits -- the table format hvlc_encode takes.
- * Any Huffman code has the same total cost as the reference's table; the codewords themselves differ. */
+ * load_data.h:40-47): Huffman code lengths (symbols with count 0 get length 0 = emit nothing); when the Huffman tree is
+ * deeper than max_len (8..31) the OPTIMAL code with lengths <= max_len (package-merge); canonical codewords
+ * right-aligned in `length` bits -- the table format hvlc_encode takes.  A Huffman code has the same total cost as the
+ * reference's table whenever the reference's own tree fits max_len; the codewords themselves differ.
+ * HVLC_ERR_ARG if the counts do not sum below 2^64. */
 int hvlc_build_table(const uint64_t* hist, uint32_t max_len, uint32_t* codewords, uint32_t* codewordlens);
 
 /* SURVEY.md section 8(f) #1 -- seam merge / contiguous stream materialisation.  Copies the `nbits` bits of a

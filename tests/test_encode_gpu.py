@@ -324,6 +324,25 @@ def test_timeout_is_reported_not_a_hang(golden, monkeypatch):
     e3.close()
 
 
+def test_scan_timeout_is_reported_by_finish(monkeypatch):
+    """hvlc_exclusive_scan is asynchronous like hvlc_encode: a look-back that gives up (test hook: scan tile 3 never
+    publishes its sum) is reported by hvlc_finish as HVLC_ERR_TIMEOUT, and the next scan on the context is clean."""
+    monkeypatch.setenv("HVLC_TIMEOUT_MS", "200")
+    e2 = hvlc.Encoder(0, 1 << 20)
+    counts = torch.randint(0, 5000, (4096 * 40 + 17,), dtype=torch.int32, device="cuda")
+    e2.test_hook(hvlc.HOOK_STALL_TILE, 3)
+    e2.exclusive_scan(counts)
+    _, rc = e2.finish(check=False)
+    assert rc == hvlc.ERR_TIMEOUT, rc
+    e2.test_hook(hvlc.HOOK_STALL_TILE, -1)
+    offs, total = e2.exclusive_scan(counts)
+    tot, rc = e2.finish(check=False)
+    ref = torch.cumsum(counts.to(torch.int64), 0)
+    assert rc == 0 and tot == int(ref[-1].item()) == int(total.item())
+    assert torch.equal(offs[1:], ref[:-1]) and int(offs[0].item()) == 0
+    e2.close()
+
+
 @pytest.mark.parametrize("extra_words", [1, 1234, 7167])
 def test_partial_last_tile_behind_a_busy_ring(enc, golden, extra_words):
     """The tile the input ends in takes the general path while its workgroup still holds packed tiles in the

@@ -92,7 +92,35 @@ def test_c_abi_table_builder_matches_the_python_one(golden):
         cw, cl = hvlc.build_table(fib, ml)
         assert cl.max() <= ml and _prefix_free(cw, cl) and sum(2.0 ** -int(l) for l in cl if l) <= 1.0 + 1e-12
         assert (cw < (np.uint64(1) << cl.astype(np.uint64))).all()
+        pw, pl = hvlc.huffman_table(fib, ml)
+        assert np.array_equal(cl, pl) and np.array_equal(cw, pw)
     # the reference's table has the same cost on its own test file
     hist = np.bincount(np.tile(golden["period"], 4), minlength=256).astype(np.uint64)
     _, cl = hvlc.build_table(hist)
     assert int((hist * cl).sum()) == int((hist * golden["cl"]).sum())
+
+
+def test_length_limited_tables_are_optimal_not_just_valid():
+    """A limit that bites must cost next to nothing when the excess is tiny (a geometric histogram: the unlimited code
+    is 1, 2, 3, ... bits deep; limiting 40 symbols to 31 bits touches only symbols of probability < 2^-30) and the Kraft
+    sum must stay 1 (no slack given away)."""
+    for nsym, ml in ((40, 31), (30, 12), (60, 16)):
+        h = np.zeros(256, dtype=np.uint64)
+        for i in range(nsym):
+            h[i] = 1 << (nsym - i)
+        unl = hvlc.huffman_lengths(h, 255)             # deep enough for any 256-symbol tree: the unlimited Huffman code
+        assert unl.max() > ml
+        cw, cl = hvlc.build_table(h, ml)
+        assert cl.max() <= ml and _prefix_free(cw, cl) and ((cl > 0) == (h > 0)).all()
+        assert abs(sum(2.0 ** -int(l) for l in cl if l) - 1.0) < 1e-12
+        cost, best = int((h * cl.astype(np.uint64)).sum()), int((h * unl.astype(np.uint64)).sum())
+        assert best <= cost <= best * 1.01, (nsym, ml, cost, best)
+        assert cl[0] == unl[0] == 1                    # the most frequent symbol keeps its 1-bit code
+    # brute force on a small alphabet: package-merge is optimal among all length assignments with Kraft sum <= 1
+    import itertools
+    h = np.zeros(256, dtype=np.uint64); h[:6] = [50, 20, 10, 5, 2, 1]
+    _, cl = hvlc.build_table(h, 8)                     # (limit 8 does not bite: plain Huffman)
+    small = hvlc.huffman_lengths(list(h), 3)           # 6 symbols in <= 3 bits
+    best = min(sum(int(h[i]) * l[i] for i in range(6)) for l in itertools.product(range(1, 4), repeat=6)
+               if sum(2.0 ** -x for x in l) <= 1.0)
+    assert small.max() <= 3 and int((h * small.astype(np.uint64)).sum()) == best
