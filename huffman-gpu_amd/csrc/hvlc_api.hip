@@ -39,6 +39,7 @@ struct hvlc_ctx {
     uint64_t  granule_bytes = 0;         // capacity of the granule region
     uint64_t  timeout_ticks = 200000000ull;   // 2 s of the 100 MHz real-time counter
     int       scan_blocks_per_cu = 0;        // k_exclusive_scan occupancy on this device (picked on first use)
+    bool      decode_lds_set = false;        // k_decode's dynamic LDS size registered on this device
     // test hooks (hvlc_test_hook; never set in production)
     uint32_t  hook_stall_tile = ~0u;
     int       hook_force_grid = 0;
@@ -610,10 +611,14 @@ int hvlc_decode(hvlc_ctx* c, const uint32_t* d_bits, uint64_t total_bits, const 
     if (num_words == 0) return HVLC_OK;
     HVLC_HIP(c, hipSetDevice(c->device));
     const uint64_t segs = hvlc_num_segments(num_words);
-    uint64_t grid = (segs + kThreads - 1) / kThreads;
-    const uint64_t cap = (uint64_t)c->cus * 4;
+    uint64_t grid = (segs + kDecThreads - 1) / kDecThreads;      // one lane per segment
+    const uint64_t cap = (uint64_t)c->cus;                       // one 16-wave workgroup per CU (146 KiB of LDS)
     if (grid > cap) grid = cap;
-    HVLC_HIP(c, launch(k_decode, dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)stream,
+    if (!c->decode_lds_set) {                                    // more than 64 KiB of dynamic LDS has to be asked for
+        HVLC_HIP(c, hipFuncSetAttribute((const void*)k_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DecSmem)));
+        c->decode_lds_set = true;
+    }
+    HVLC_HIP(c, launch(k_decode, dim3((unsigned)grid), dim3(kDecThreads), sizeof(DecSmem), (hipStream_t)stream,
                        d_bits, total_bits, d_offsets, segs, d_codewords, d_codewordlens, d_out_words, num_words));
     return HVLC_OK;
 }

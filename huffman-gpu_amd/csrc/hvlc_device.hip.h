@@ -1425,85 +1425,203 @@ __global__ void __launch_bounds__(kThreads) k_merge_shard(const uint32_t* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// SURVEY.md section 8(f) #3 -- decoder (the reference has none; it exists to prove round trips).  One thread per
-// 1024-byte segment, starting at the segment's bit offset.  Codes of up to kDecBits bits resolve with one LDS
-// lookup of the next kDecBits stream bits; longer ones by a linear search over the (few) long codes.
-// Precondition: a prefix-free table; symbols with length 0 cannot be decoded.
+// SURVEY.md section 8(f) #3 -- decoder (the reference has none; it exists to prove round trips and to read the format
+// back).  One LANE per 1024-byte segment, started at the segment's bit offset; a wave owns 64 consecutive segments
+// (64 KiB of output, one contiguous span of the stream).
+//   stream    every lane keeps the next words of ITS part of the span in a 16-dword ring in LDS (dword-major:
+//             ring[slot][lane], conflict-free whatever slot each lane is at).  Every 16 symbols the wave tops the rings up:
+//             a lane whose ring holds fewer than 8 words ahead loads the next aligned 16 bytes -- every stream byte is
+//             loaded once, and neighbouring lanes' parts are adjacent, so the lines are shared through L2.
+//   symbols   four symbols per 64-bit bit buffer (4 x kDecBits <= 64), straight-line and branch-free: codes of up to
+//             kDecBits bits resolve with ONE LDS lookup of the next kDecBits stream bits; a longer code reads as length 0,
+//             is noticed once per word, and that lane decodes the word again symbol by symbol (long codes: a list in
+//             order of length, searched linearly)
+//   output    16 words per lane are staged in LDS (odd row stride: conflict-free writes) and flushed with dwordx4 stores:
+//             one instruction writes 64 contiguous bytes of each of 16 segments
+// One 16-wave workgroup per CU shares the 16 KiB table.  Precondition: a prefix-free table; symbols with length 0 cannot
+// be decoded.  An invalid stream or table yields wrong symbols, never an access outside the stream / output buffers.
 // ---------------------------------------------------------------------------------------------
-constexpr int kDecBits  = 12;
-constexpr int kDecChunk = 32;                  // words a thread decodes between two coalesced flushes of its wave
-__global__ void __launch_bounds__(kThreads) k_decode(const uint32_t* __restrict__ bits, uint64_t total_bits,
-                                                     const uint64_t* __restrict__ offsets, uint64_t num_segs,
-                                                     const uint32_t* __restrict__ cw, const uint32_t* __restrict__ cl,
-                                                     uint32_t* __restrict__ out, uint64_t num_words)
+constexpr int kDecBits    = 13;                // first-level table: 8192 x 2 bytes
+constexpr int kDecWaves   = 16;
+constexpr int kDecThreads = 64 * kDecWaves;
+constexpr int kDecTop     = 4;                 // words (x4 symbols) between two top-ups of the rings
+constexpr int kDecChunk   = 16;                // words per lane between two flushes
+constexpr int kDecRing    = 16;                // ring dwords per lane
+constexpr int kDecAhead   = 8;                 // words a ring must hold ahead of the read position at a top-up
+constexpr int kDecStride  = 17;                // LDS words per lane in the output staging area
+static_assert((31 + (kDecTop * 4 - 4) * kDecBits) / 32 + 2 < kDecAhead, "short codes cannot outrun the ring between two top-ups");
+static_assert(kDecAhead + 3 + 4 <= kDecRing, "a top-up never overwrites words still to be read");
+
+struct alignas(16) DecSmem {
+    uint16_t fast[1 << kDecBits];              // (length << 8) | symbol, 0 = a longer code
+    uint32_t lcode[256];                       // long codes, left-aligned in 32 bits, in order of length
+    uint8_t  llen[256], lsym[256];
+    uint32_t nlong, pad_[3];
+    uint32_t ring[kDecWaves][kDecRing][64];    // stream words, dword-major
+    uint32_t stage[kDecWaves][64][kDecStride]; // decoded words
+};
+
+__device__ __forceinline__ uint32_t dec_word(const uint32_t* __restrict__ bits, uint64_t total_words, uint64_t wi)
 {
-    __shared__ uint16_t fast[1 << kDecBits];         // (symbol << 8) | length, 0 = a longer code
-    __shared__ uint32_t lcode[256];                  // long codes, left-aligned in 32 bits
-    __shared__ uint8_t  llen[256], lsym[256];
-    __shared__ uint32_t nlong;
-    __shared__ uint32_t stage[4][64][kDecChunk + 1]; // per wave: a chunk of every lane's output (+1: bank stagger)
-    for (int i = threadIdx.x; i < (1 << kDecBits); i += kThreads) fast[i] = 0;
-    if (threadIdx.x == 0) nlong = 0;
-    __syncthreads();
-    {
+    return wi < total_words ? bits[wi] : 0u;
+}
+
+__global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restrict__ bits, uint64_t total_bits,
+                                                        const uint64_t* __restrict__ offsets, uint64_t num_segs,
+                                                        const uint32_t* __restrict__ cw, const uint32_t* __restrict__ cl,
+                                                        uint32_t* __restrict__ out, uint64_t num_words)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dec_smem_raw[];
+    DecSmem& sm = *reinterpret_cast<DecSmem*>(dec_smem_raw);
+    // ---- tables.  Short codes: every table index that starts with the code gets (length << 8) | symbol; the indices
+    // of one symbol are filled by all threads together (a 1-bit code owns half the table).  Long codes: a list ordered
+    // by length (the likelier first), searched linearly.
+    __shared__ uint32_t t_len[256], t_code[256];
+    for (int i = threadIdx.x; i < (1 << kDecBits); i += kDecThreads) sm.fast[i] = 0;
+    if (threadIdx.x < 256) {
         const uint32_t len = cl[threadIdx.x];
-        const uint32_t c = len >= 1 && len <= 31u ? (cw[threadIdx.x] & ((1u << len) - 1u)) : 0u;   // an invalid table must not index out of range
-        if (len >= 1 && len <= (uint32_t)kDecBits) {
-            const uint32_t base = c << (kDecBits - len), n = 1u << (kDecBits - len);
-            for (uint32_t i = 0; i < n; ++i) fast[base + i] = (uint16_t)((threadIdx.x << 8) | len);
-        } else if (len > (uint32_t)kDecBits && len <= 31u) {
-            const uint32_t k = atomicAdd(&nlong, 1u);
-            lcode[k] = c << (32u - len); llen[k] = (uint8_t)len; lsym[k] = (uint8_t)threadIdx.x;
-        }
+        t_len[threadIdx.x]  = len <= 31u ? len : 0u;
+        t_code[threadIdx.x] = len >= 1 && len <= 31u ? (cw[threadIdx.x] & ((1u << len) - 1u)) : 0u;   // an invalid table must not index out of range
     }
     __syncthreads();
+    for (int sy = 0; sy < 256; ++sy) {
+        const uint32_t len = t_len[sy];
+        if (len >= 1u && len <= (uint32_t)kDecBits) {
+            const uint32_t base = t_code[sy] << (kDecBits - len), n = 1u << (kDecBits - len);
+            for (uint32_t i = threadIdx.x; i < n; i += kDecThreads) sm.fast[base + i] = (uint16_t)((len << 8) | (uint32_t)sy);
+        }
+    }
+    if (threadIdx.x < 256) {
+        const uint32_t len = t_len[threadIdx.x];
+        uint32_t before = 0, total = 0;
+        for (int o = 0; o < 256; ++o) {
+            const uint32_t lo = t_len[o];
+            if (lo > (uint32_t)kDecBits) { ++total; if (lo < len || (lo == len && o < (int)threadIdx.x)) ++before; }
+        }
+        if (len > (uint32_t)kDecBits) {
+            sm.lcode[before] = t_code[threadIdx.x] << (32u - len); sm.llen[before] = (uint8_t)len; sm.lsym[before] = (uint8_t)threadIdx.x;
+        }
+        if (threadIdx.x == 0) sm.nlong = total;
+    }
+    __syncthreads();
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t total_words = (total_bits >> 5) + 1;
+    const uint32_t nl = sm.nlong;
+    uint32_t (*const ring)[64] = sm.ring[wave];
+    uint32_t (*const my)[kDecStride] = sm.stage[wave];
     // a wave owns 64 consecutive segments; all its lanes run the same number of chunks (a wave-uniform loop)
-    for (uint64_t seg0 = ((uint64_t)blockIdx.x * 4 + wave) * 64; seg0 < num_segs; seg0 += (uint64_t)gridDim.x * 256) {
+    for (uint64_t seg0 = ((uint64_t)blockIdx.x * kDecWaves + wave) * 64; seg0 < num_segs; seg0 += (uint64_t)gridDim.x * kDecWaves * 64) {
         const uint64_t seg = seg0 + (uint64_t)lane;
-        const bool live = seg < num_segs;
-        // 64-bit left-aligned bit buffer, refilled 32 bits at a time
-        uint64_t buf = 0; uint32_t avail = 0; uint64_t next = 0;
-        if (live) {
-            const uint64_t pos = offsets[seg];
-            const uint64_t wi = pos >> 5; const uint32_t skip = (uint32_t)pos & 31u;
-            const uint32_t w0 = wi < total_words ? bits[wi] : 0u, w1 = wi + 1 < total_words ? bits[wi + 1] : 0u;
-            buf = (((uint64_t)w0 << 32) | (uint64_t)w1) << skip;
-            avail = 64u - skip; next = wi + 2;
-        }
+        const uint64_t pos = seg < num_segs ? offsets[seg] : 0ull;
+        const uint64_t wbase = (pos >> 5) & ~3ull;   // ring word 0 (16-byte aligned in the stream); positions are relative to it
+        uint32_t pb   = (uint32_t)(pos - wbase * 32u);   // the lane's read position in bits (a segment holds < 2^15 bits)
+        uint32_t have = 0;                           // words [have - kDecRing, have) are in the ring (a multiple of 4)
+        // the 64 stream bits at bit q, left-aligned: from the ring, or (a lane that long codes took past it) from memory
+        auto bits64_at = [&](uint32_t q) -> uint64_t {
+            const uint32_t kk = q >> 5, sh = q & 31u;
+            uint32_t w0, w1, w2;
+            if (kk + 2u < have) { w0 = ring[kk & (kDecRing - 1)][lane]; w1 = ring[(kk + 1) & (kDecRing - 1)][lane]; w2 = ring[(kk + 2) & (kDecRing - 1)][lane]; }
+            else {
+                w0 = dec_word(bits, total_words, wbase + kk); w1 = dec_word(bits, total_words, wbase + kk + 1);
+                w2 = dec_word(bits, total_words, wbase + kk + 2);
+            }
+            return ((((uint64_t)w0 << 32) | (uint64_t)w1) << sh) | (((uint64_t)w2 << sh) >> 32);
+        };
         for (int chunk = 0; chunk < kSegWords / kDecChunk; ++chunk) {
-            if (live) {
-                for (int k = 0; k < kDecChunk; ++k) {
-                    uint32_t word = 0;
+#pragma unroll 1
+            for (int top = 0; top < kDecChunk / kDecTop; ++top) {
+                // ---- top up: every lane whose ring holds fewer than kDecAhead words ahead loads its next aligned 16 bytes
+                // (a lane that long codes took far ahead skips the words it will never read)
+                if (have + kDecRing < (pb >> 5)) have = (pb >> 5) & ~3u;
+                while (__any(have < (pb >> 5) + (uint32_t)kDecAhead)) {
+                    if (have < (pb >> 5) + (uint32_t)kDecAhead) {
+                        const uint64_t wi = wbase + have;
+                        u32x4 v;
+                        if (wi + 4 <= total_words) v = *(const u32x4*)(bits + wi);
+                        else { v.x = dec_word(bits, total_words, wi); v.y = dec_word(bits, total_words, wi + 1);
+                               v.z = dec_word(bits, total_words, wi + 2); v.w = dec_word(bits, total_words, wi + 3); }
+                        const uint32_t sl = have & (kDecRing - 1);
+                        ring[sl][lane] = v.x; ring[sl + 1][lane] = v.y; ring[sl + 2][lane] = v.z; ring[sl + 3][lane] = v.w;
+                        have += 4;
+                    }
+                }
+                // (same lane, same wave: LDS operations complete in order, no barrier)
+#pragma unroll 1
+                for (int w = 0; w < kDecTop; ++w) {
+                    // four symbols per bit buffer, straight-line and branch-free: a long code reads as length 0
+                    const uint32_t p0 = pb, kk = pb >> 5, sh = pb & 31u;
+                    const uint32_t w0 = ring[kk & (kDecRing - 1)][lane], w1 = ring[(kk + 1) & (kDecRing - 1)][lane],
+                                   w2 = ring[(kk + 2) & (kDecRing - 1)][lane];
+                    uint64_t buf = ((((uint64_t)w0 << 32) | (uint64_t)w1) << sh) | (((uint64_t)w2 << sh) >> 32);
+                    uint32_t word = 0, shortest = 255u;
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        if (avail <= 32u) {
-                            const uint32_t w = next < total_words ? bits[next] : 0u;
-                            buf |= (uint64_t)w << (32u - avail);
-                            avail += 32u; ++next;
-                        }
-                        const uint32_t win = (uint32_t)(buf >> 32);
-                        const uint32_t e = fast[win >> (32 - kDecBits)];
-                        uint32_t sym = e >> 8, len = e & 255u;
-                        if (len == 0u) {             // a long code (or an invalid stream: then symbol 0, one bit)
-                            len = 1u; sym = 0u;
-                            for (uint32_t q = 0; q < nlong; ++q) {
-                                const uint32_t L = llen[q];
-                                if (((win ^ lcode[q]) >> (32u - L)) == 0u) { len = L; sym = lsym[q]; break; }
+                        const uint32_t e = sm.fast[(uint32_t)(buf >> (64 - kDecBits))];
+                        const uint32_t len = e >> 8;
+                        word = (word << 8) | (e & 255u);            // most significant byte first (cpuencode.cpp:28)
+                        buf <<= len; pb += len;
+                        shortest = min(shortest, len);
+                    }
+                    const bool redo = shortest == 0u || kk + 2u >= have;     // a long code, or the lane is past its ring
+                    if (__any(redo)) {
+                        const bool far = redo && kk + 6u >= have;            // (even a redo from the ring could run out of it)
+                        if (redo && !far) {          // cold: this lane decodes the word again, symbol by symbol, from its ring
+                            pb = p0; word = 0;
+#pragma unroll 1
+                            for (int b = 0; b < 4; ++b) {
+                                const uint32_t k2 = pb >> 5, s2 = pb & 31u;
+                                const uint32_t x0 = ring[k2 & (kDecRing - 1)][lane], x1 = ring[(k2 + 1) & (kDecRing - 1)][lane];
+                                const uint32_t win2 = (uint32_t)(((((uint64_t)x0 << 32) | (uint64_t)x1) << s2) >> 32);   // 32 bits: a whole code
+                                const uint32_t e = sm.fast[win2 >> (32 - kDecBits)];
+                                uint32_t sym = e & 255u, len = e >> 8;
+                                if (len == 0u) {     // a long code (or an invalid stream: then symbol 0, one bit)
+                                    len = 1u; sym = 0u;
+                                    for (uint32_t q = 0; q < nl; ++q) {
+                                        const uint32_t L = sm.llen[q];
+                                        if (((win2 ^ sm.lcode[q]) >> (32u - L)) == 0u) { len = L; sym = sm.lsym[q]; break; }
+                                    }
+                                }
+                                pb += len;
+                                word = (word << 8) | sym;
                             }
                         }
-                        buf <<= len; avail -= len;
-                        word = (word << 8) | sym;    // most significant byte first (cpuencode.cpp:28)
+                        if (__any(far)) {
+                            if (far) {               // colder: the same with reads that may go to memory
+                                pb = p0; word = 0;
+#pragma unroll 1
+                                for (int b = 0; b < 4; ++b) {
+                                    const uint32_t win2 = (uint32_t)(bits64_at(pb) >> 32);
+                                    const uint32_t e = sm.fast[win2 >> (32 - kDecBits)];
+                                    uint32_t sym = e & 255u, len = e >> 8;
+                                    if (len == 0u) {
+                                        len = 1u; sym = 0u;
+                                        for (uint32_t q = 0; q < nl; ++q) {
+                                            const uint32_t L = sm.llen[q];
+                                            if (((win2 ^ sm.lcode[q]) >> (32u - L)) == 0u) { len = L; sym = sm.lsym[q]; break; }
+                                        }
+                                    }
+                                    pb += len;
+                                    word = (word << 8) | sym;
+                                }
+                            }
+                        }
                     }
-                    stage[wave][lane][k] = word;
+                    my[lane][top * kDecTop + w] = word;
                 }
             }
-            // coalesced flush: one store instruction writes the chunks of two lanes (2 x 128 contiguous bytes)
-            for (int pr = 0; pr < 32; ++pr) {
-                const int j = 2 * pr + (lane >> 5), k = lane & 31;
-                const uint64_t w = (seg0 + (uint64_t)j) * kSegWords + (uint64_t)chunk * kDecChunk + (uint64_t)k;
-                if (w < num_words) out[w] = stage[wave][j][k];   // (lanes of one wave: LDS operations complete in order)
+            // flush: instruction t writes words 4(l%4)..4(l%4)+3 of segments 16t + l/4: 64 contiguous bytes per segment
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = 16 * t + (lane >> 2), q4 = (lane & 3) * 4;
+                const uint4 v = make_uint4(my[j][q4], my[j][q4 + 1], my[j][q4 + 2], my[j][q4 + 3]);
+                const uint64_t wo = (seg0 + (uint64_t)j) * kSegWords + (uint64_t)chunk * kDecChunk + (uint64_t)q4;
+                if (wo + 3 < num_words) *reinterpret_cast<uint4*>(out + wo) = v;
+                else {
+                    if (wo     < num_words) out[wo]     = v.x;
+                    if (wo + 1 < num_words) out[wo + 1] = v.y;
+                    if (wo + 2 < num_words) out[wo + 2] = v.z;
+                }
             }
         }
     }
