@@ -531,6 +531,12 @@ __device__ __forceinline__ void load_tile(const EncodeParams& p, uint32_t tile, 
     }
 }
 
+// Does wave `wave`'s part (kRows segments) of `tile` lie completely inside the input?  (wave-uniform)
+__device__ __forceinline__ bool part_is_full(const EncodeParams& p, uint32_t tile, int wave)
+{
+    return (uint64_t)tile * kTileWords + (uint64_t)(wave + 1) * (kRows * kSegWords) <= p.num_words;
+}
+
 __device__ __forceinline__ int valid_words(const EncodeParams& p, uint64_t wbase)
 {
     return wbase >= p.num_words ? 0 : (p.num_words - wbase >= 4 ? 4 : (int)(p.num_words - wbase));
@@ -616,6 +622,7 @@ __device__ __forceinline__ uint32_t chain_tail(uint32_t pred_tail, uint32_t own,
 
 // Publish the stream tail behind (tile, wave)'s part: to the next wave of the workgroup through LDS, and, for the
 // tile's last part, to the next tile's record (read by that tile's scout).
+template <bool LATE>
 __device__ __forceinline__ void publish_tail(const EncodeParams& p, Smem& sm, uint32_t slot, int wave, uint32_t tile,
                                              uint32_t tail, int lane)
 {
@@ -623,6 +630,7 @@ __device__ __forceinline__ void publish_tail(const EncodeParams& p, Smem& sm, ui
         lds_rel(&sm.wrec[slot][wave].tail, kValid32 | tail);
         if (wave == kDataWaves - 1) st_word(&p.recs[(uint64_t)tile + 1].tail, kValid32 | tail);
     }
+    if (LATE) wake_workgroup();                       // the next wave may be sleeping on it (an early tail is never waited for)
 }
 
 // The last 31 stream bits in front of (slot, wave)'s part of a RESOLVED tile: the tile's predecessor tail for wave 0,
@@ -672,7 +680,7 @@ __device__ __forceinline__ bool store_part(const EncodeParams& p, Smem& sm, uint
     if (last) nown = ((s + T + 31u) >> 5) + ((((s + T) & 31u) == 0u) ? 1u : 0u);
     store_words(p, sb, s, G >> 5, nown, lane);
     if (!(own_tail & kValid32))                                    // a part shorter than 31 bits: its tail needed the predecessor's
-        publish_tail(p, sm, slot, wave, tile, chain_tail(pt, extract_tail(sb + 1, T), T), lane);
+        publish_tail<true>(p, sm, slot, wave, tile, chain_tail(pt, extract_tail(sb + 1, T), T), lane);
     zero_words(sb, need / 4u, lane);
     return true;
 }
@@ -725,7 +733,7 @@ __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint3
         p.result[0] = G;
         if (p.total_bits) *p.total_bits = G;
     }
-    publish_tail(p, sm, slot, wave, tile, carry, lane);
+    publish_tail<true>(p, sm, slot, wave, tile, carry, lane);
     return true;
 }
 
@@ -766,7 +774,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
     auto try_load = [&]() -> bool {
         if (lds_acq(&sm.n_tickets) <= c.m_loaded) return false;
         const uint32_t t = uni(sm.tq[c.m_loaded % kTq]);
-        load_tile(p, t, t < p.num_full_tiles, wave, lane, raw);
+        load_tile(p, t, part_is_full(p, t, wave), wave, lane, raw);
         ++c.m_loaded;
         return true;
     };
@@ -798,7 +806,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         }
         const uint32_t cur  = uni(sm.tq[c.m_packed % kTq]);
         const uint32_t slot = c.m_packed % kSlots;
-        const bool full = cur < p.num_full_tiles;
+        const bool full = part_is_full(p, cur, wave);        // (only the part the input ends in, and the empty ones behind it, are not)
 
         // ---- 1: lookups, concatenation, scan (registers only)
         uint64_t acc[kRows];
@@ -812,7 +820,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
                 for (int r = 0; r < kRows; ++r) encode16<false>(raw[r], sm.lut, acc[r], tot[r]);
             }
         } else {
-            // the one tile the input ends in: bit counts only, the slow path packs it (cold code)
+            // the part the input ends in (or an empty one behind it): bit counts only, the slow path packs it (cold code)
 #pragma unroll
             for (int r = 0; r < kRows; ++r) {
                 const uint64_t wbase = (uint64_t)cur * kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
@@ -918,7 +926,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
                 }
             } else if (acc[0] + acc[1] + acc[2] + acc[3] == 0x123456789ull) st[incl[0] & 1023u] = tot[0];
             if (T >= 31u)                                // the part's last 31 bits are all its own: publish the tail now
-                publish_tail(p, sm, slot, wave, cur, extract_tail(st, T), lane);
+                publish_tail<false>(p, sm, slot, wave, cur, extract_tail(st, T), lane);
             ++c.m_packed;
             WS_LAP(kWsPack); WS_COUNT(kWsTiles);
         } else {
