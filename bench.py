@@ -105,11 +105,32 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # REHEARSAL of the N > 1 code on a one-GPU box (developer use, never the driver's run): HVLC_BENCH_REHEARSAL=1 puts
+    # every rank on cuda:0 and carries the collectives over gloo (staged through host memory); everything else is the
+    # code the 8-GPU run executes.  The JSON line says so ("rehearsal": true) and such a number is not a measurement.
+    rehearsal = os.environ.get("HVLC_BENCH_REHEARSAL", "") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def all_reduce(t, op=dist.ReduceOp.SUM):
+        if rehearsal:
+            h = t.cpu(); dist.all_reduce(h, op=op); t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
+    def all_gather_into_tensor(out_t, in_t):
+        if rehearsal:
+            ho = out_t.cpu(); dist.all_gather_into_tensor(ho, in_t.cpu()); out_t.copy_(ho)
+        else:
+            dist.all_gather_into_tensor(out_t, in_t)
 
     dname, mib, seed = WORKLOADS[args.workload]
     if args.size_mib:
@@ -125,7 +146,7 @@ def main():
     hist = enc.histogram(d_in)
     local_hist = hist.cpu().numpy().astype(np.uint64)
     if world > 1:
-        dist.all_reduce(hist)                              # table of the WHOLE job's histogram
+        all_reduce(hist)                                   # table of the WHOLE job's histogram
     hist_np = hist.cpu().numpy().astype(np.uint64)
     cw, cl = hvlc.build_table(hist_np)                     # libhvlc's host-side table builder
     max_len = int(cl.max())
@@ -143,7 +164,7 @@ def main():
         enc.encode_ptr(d_in.data_ptr(), n_words, d_table.data_ptr(), d_table.data_ptr() + 1024,
                        out.data_ptr(), out.numel(), offsets.data_ptr(), total.data_ptr())
         # the stitch: one 8-byte-per-rank exchange over xGMI + the rebase of this rank's offsets
-        hvlc.stitch(total, gathered, rank, world, dist.all_gather_into_tensor if world > 1 else None, rebase)
+        hvlc.stitch(total, gathered, rank, world, all_gather_into_tensor, rebase)
 
     def fence():
         if world > 1:
@@ -174,7 +195,7 @@ def main():
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * n_bytes / (dt / args.steps) / 1e9
@@ -196,8 +217,8 @@ def main():
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     checked = torch.tensor([(pre_bits + 7) // 8], dtype=torch.int64, device=dev)
     if world > 1:
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        dist.all_reduce(checked)
+        all_reduce(flag, op=dist.ReduceOp.MIN)
+        all_reduce(checked)
     bit_exact = bool(flag.item())
     checked_bytes = int(checked.item())
 
@@ -258,6 +279,7 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "bit_exact": bit_exact, "checked_bytes": checked_bytes,
+            **({"rehearsal": True} if rehearsal else {}),
             "config": {"workload": f"{mib} MiB/GPU synthetic {dname} byte stream (splitmix64 seed {seed:#x}), "
                                    f"Huffman table of the job histogram (max len {max_len}); stream prefix compared word for word "
                                    f"with cpu_vlc_encode ({'reference' if use_ref else 'port'}) after the timed region",
