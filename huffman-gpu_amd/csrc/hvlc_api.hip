@@ -687,8 +687,8 @@ int hvlc_histogram(hvlc_ctx* c, const uint8_t* d_data, uint64_t n_bytes, uint64_
     hipStream_t s = (hipStream_t)stream;
     HVLC_HIP(c, hipMemsetAsync(d_hist, 0, 256 * 8, s));
     if (n_bytes == 0) return HVLC_OK;
-    // >= 1 block per 64 MiB keeps every 32-bit LDS bin far from overflow; 8 blocks per CU fill the chip
-    uint64_t grid = (uint64_t)c->cus * 8;
+    // >= 1 block per 64 MiB keeps every 32-bit LDS bin far from overflow
+    uint64_t grid = (uint64_t)c->cus * 4;   // four 33-KiB workgroups per CU
     const uint64_t need = n_bytes / (64ull << 20) + 1;
     if (grid < need) grid = need;
     const uint64_t maxb = (n_bytes / 16 + kThreads - 1) / kThreads + 1;

@@ -1728,15 +1728,15 @@ __global__ void __launch_bounds__(kThreads) k_gen_symbols(uint32_t* out, uint64_
 }
 
 // Byte histogram, one HBM pass.  Skewed data makes most lanes of a wave hit the same few bins, and LDS atomics on
-// one address serialise: every wave keeps kHistCopies private copies of the histogram (lane % kHistCopies picks
-// one), staggered by one word so that the same bin of different copies falls into different LDS banks.
-constexpr int kHistCopies = 8;
+// one address serialise: the workgroup keeps kHistCopies copies of the histogram, lane % kHistCopies picks one (two
+// lanes of a wave per copy), staggered by one word so that the same bin of the 32 copies falls into 32 different banks.
+constexpr int kHistCopies = 32;
 __global__ void __launch_bounds__(kThreads) k_histogram(const uint8_t* data, uint64_t n_bytes, unsigned long long* hist)
 {
-    __shared__ uint32_t h[4][kHistCopies][257];
-    for (int i = threadIdx.x; i < 4 * kHistCopies * 257; i += kThreads) (&h[0][0][0])[i] = 0u;
+    __shared__ uint32_t h[kHistCopies][257];
+    for (int i = threadIdx.x; i < kHistCopies * 257; i += kThreads) (&h[0][0])[i] = 0u;
     __syncthreads();
-    uint32_t* mine = h[threadIdx.x >> 6][threadIdx.x & (kHistCopies - 1)];
+    uint32_t* mine = h[threadIdx.x & (kHistCopies - 1)];
     const uint64_t nvec = n_bytes / 16;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4* v = (const u32x4*)data;
@@ -1756,9 +1756,7 @@ __global__ void __launch_bounds__(kThreads) k_histogram(const uint8_t* data, uin
     __syncthreads();
     uint32_t s = 0;
 #pragma unroll
-    for (int w2 = 0; w2 < 4; ++w2)
-#pragma unroll
-        for (int c2 = 0; c2 < kHistCopies; ++c2) s += h[w2][c2][threadIdx.x];
+    for (int c2 = 0; c2 < kHistCopies; ++c2) s += h[c2][threadIdx.x];
     if (s) atomicAdd(&hist[threadIdx.x], (unsigned long long)s);
 }
 
