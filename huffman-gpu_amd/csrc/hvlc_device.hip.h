@@ -628,7 +628,17 @@ __device__ __forceinline__ void publish_tail(const EncodeParams& p, Smem& sm, ui
 {
     if (lane == 0) {
         lds_rel(&sm.wrec[slot][wave].tail, kValid32 | tail);
-        if (wave == kDataWaves - 1) st_word(&p.recs[(uint64_t)tile + 1].tail, kValid32 | tail);
+        int last = wave;
+        if (LATE) {
+            // A late tail is published when the tile is resolved, so every part's bit count is known: EMPTY parts behind
+            // this one end in the same 31 bits -- publish for them too instead of handing the tail from wave to wave
+            // (the end of the input: the parts behind the one the input ends in).  They may publish the same value again.
+            while (last + 1 < kDataWaves && sm.wrec[slot][last + 1].bits == 0u) {
+                ++last;
+                lds_rel(&sm.wrec[slot][last].tail, kValid32 | tail);
+            }
+        }
+        if (last == kDataWaves - 1) st_word(&p.recs[(uint64_t)tile + 1].tail, kValid32 | tail);
     }
     if (LATE) wake_workgroup();                       // the next wave may be sleeping on it (an early tail is never waited for)
 }
