@@ -296,7 +296,6 @@ int hvlc_encode(hvlc_ctx* c,
     EncodeParams p;
     memset(&p, 0, sizeof(p));
     p.in = (const uint4*)d_in;  p.num_words = num_words;  p.num_tiles = tiles;
-    p.num_full_tiles = (uint32_t)(num_words / kTileWords);
     p.num_segs = hvlc_num_segments(num_words);
     p.lut = ws_lut(c);  p.out = d_out_bits;  p.out_cap = out_capacity_words;
     p.offsets = d_out_offsets;  p.total_bits = d_total_bits;

@@ -62,7 +62,6 @@ constexpr int      kEncThreads  = kDataThreads + 64;       // k_encode: 7+1 wave
 #endif
 constexpr int      kRows        = HVLC_ROWS;               // 16-byte rows per lane per tile
 constexpr int      kTileWords   = kDataThreads * kRows * 4;   // 7168 words = 28 KiB
-constexpr int      kTileVec     = kDataThreads * kRows;    // uint4s per tile
 constexpr int      kSegWords    = 256;
 constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 28: wave w owns segments 4w..4w+3
 #ifndef HVLC_GROUP_TILES
@@ -95,7 +94,6 @@ struct EncodeParams {
     const uint4*    in;          // input words, 16-byte aligned
     uint64_t        num_words;
     uint64_t        num_tiles;
-    uint32_t        num_full_tiles;  // tiles that lie completely inside the input (num_words / kTileWords)
     uint64_t        num_segs;
     const uint2*    lut;         // {codeword (masked), length} x 256, built by k_prepare
     uint32_t*       out;         // final stream
@@ -117,7 +115,7 @@ struct EncodeParams {
 };
 
 // Ablation switches for tools/ablate.py.  In the product build HVLC_DBG() is a compile-time false.
-enum : uint32_t { kDbgNoLookback = 1u, kDbgNoStore = 2u, kDbgNoPack = 4u, kDbgNoLookup = 8u, kDbgNoOffsets = 16u };
+enum : uint32_t { kDbgNoLookback = 1u, kDbgNoStore = 2u, kDbgNoPack = 4u, kDbgNoOffsets = 16u };
 #ifdef HVLC_EXPERIMENT
 #define HVLC_DBG(p, bit) (((p).dbg & (bit)) != 0u)
 #define TL(p, tile, k, cond) do { if ((p).dbg_tl && (cond)) (p).dbg_tl[(uint64_t)(tile) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -275,7 +273,7 @@ __device__ __forceinline__ uint32_t extract_tail(const uint32_t* st, uint32_t e)
 // symbol -> codeword lookup and concatenation of one lane-row (16 bytes = 4 words = 16 symbols,
 // most significant byte of each word first: cpuencode.cpp:28, vlc_kernel_sm64huff.cu:67).
 // acc is only meaningful while tot <= 64 (the reference's cw64 limit is per WORD,
-// vlc_kernel_sm64huff.cu:48,70; here it is per 16 symbols and checked, with a general path).
+// vlc_kernel_sm64huff.cu:48,70; here it is per 16 symbols and checked, with a pairwise cold path).
 // ---------------------------------------------------------------------------------------------
 //
 // The table sits in LDS at slot(s) = s ^ (s >> 4): symbol sets with a power-of-two stride (e.g. the
@@ -1223,7 +1221,7 @@ k_encode(EncodeParams p)
         for (uint32_t i = (uint32_t)tid; i < nvec; i += (uint32_t)kEncThreads) z[i] = make_uint4(0, 0, 0, 0);
     }
     if (blockIdx.x >= (uint32_t)p.num_tiles) return;
-    __syncthreads();                                  // the only workgroup-wide barrier: LDS initialised
+    __syncthreads();                                  // the only workgroup-wide barriers: LDS initialised
     if (tid == 0) sm.n_final = ~0u;
     __syncthreads();
 #ifdef HVLC_PRIO_YOUNG
