@@ -53,9 +53,10 @@ struct hvlc_ctx {
 
 namespace {
 
-constexpr uint64_t kLutBytes    = 2048;
-constexpr uint64_t kStatusBytes = 64;
-constexpr uint64_t kHeaderBytes = kLutBytes + kStatusBytes;
+constexpr uint64_t kLutBytes    = kWsLutBytes;      // the layout of the workspace is the device header's (EncodeParams)
+constexpr uint64_t kStatusBytes = kWsStatusBytes;
+constexpr uint64_t kHeaderBytes = kWsHeaderBytes;
+static_assert(kWsOffBits32 == kTicketClasses * kTicketStride * 4, "ticket counters sit in front of bits32");
 
 #define HVLC_HIP(ctx, call)                                   \
     do {                                                      \
@@ -119,18 +120,13 @@ inline uint8_t*  ws_gran(hvlc_ctx* c)   { return c->ws + kHeaderBytes; }
 void fill_granule_ptrs(hvlc_ctx* c, uint64_t tiles, EncodeParams& p, bool scan)
 {
     const Layout l = layout_for(tiles);
-    uint8_t* g = ws_gran(c);
+    p.ws = c->ws;                       // offsets fit 32 bits: 16 bytes of records per 28 KiB tile
     if (scan) {
-        p.tile_bits  = (uint64_t*)g;
-        p.group_desc = (uint64_t*)(g + l.scan_off_groups);
+        p.off_groups = (uint32_t)l.scan_off_groups;
     } else {
-        p.tickets    = (uint32_t*)(g + l.off_tickets);
-        p.bits32     = (uint32_t*)(g + l.off_bits32);
-        p.recs       = (TileRec*)(g + l.off_recs);
-        p.group_desc = (uint64_t*)(g + l.off_groups);
+        p.off_recs   = (uint32_t)l.off_recs;
+        p.off_groups = (uint32_t)l.off_groups;
     }
-    p.status     = ws_status(c);
-    p.result     = ws_result(c);
     p.timeout_ticks = c->timeout_ticks;
 }
 
@@ -297,7 +293,7 @@ int hvlc_encode(hvlc_ctx* c,
     memset(&p, 0, sizeof(p));
     p.in = (const uint4*)d_in;  p.num_words = num_words;  p.num_tiles = tiles;
     p.num_segs = hvlc_num_segments(num_words);
-    p.lut = ws_lut(c);  p.out = d_out_bits;  p.out_cap = out_capacity_words;
+    p.out = d_out_bits;  p.out_cap = out_capacity_words;
     p.offsets = d_out_offsets;  p.total_bits = d_total_bits;
     fill_granule_ptrs(c, tiles, p, false);
     p.stall_tile = c->hook_stall_tile;                        // ~0 unless a test set it (hvlc_test_hook)

@@ -90,28 +90,46 @@ constexpr uint32_t kValid32 = 1u << 31;
 
 enum : uint32_t { kFlagTable = 1u, kFlagCapacity = 2u, kFlagTimeout = 4u, kFlagLayout = 8u };
 
+// Workspace of a context, one allocation: [table 2 KiB][status / result 64 B][granule area ...].  The kernels get ONE
+// base pointer and two byte offsets instead of eight pointers (fewer live scalar registers in k_encode: with eight, the
+// compiler spilled pointers to VGPR lanes and reloaded them in front of the polls).
+constexpr uint32_t kWsLutBytes    = 2048;
+constexpr uint32_t kWsStatusBytes = 64;      // uint32 [0] flags, [1] table layout, uint64 at +8: total bits / scan total
+constexpr uint32_t kWsHeaderBytes = kWsLutBytes + kWsStatusBytes;
+constexpr uint32_t kWsOffBits32   = 64 * 32 * 4;   // granule area: tickets [64 x 128 B] | bits32 | recs | group_desc
+
 struct EncodeParams {
     const uint4*    in;          // input words, 16-byte aligned
     uint64_t        num_words;
     uint64_t        num_tiles;
     uint64_t        num_segs;
-    const uint2*    lut;         // {codeword (masked), length} x 256, built by k_prepare
     uint32_t*       out;         // final stream
     uint64_t        out_cap;     // words
     uint64_t*       offsets;     // per-segment exclusive bit offsets (nullable)
     uint64_t*       total_bits;  // user's device word (nullable)
-    uint64_t*       result;      // workspace: [0] total bits
-    uint32_t*       status;      // workspace: flag word
-    uint32_t*       tickets;     // encoder: kTicketClasses counters, kTicketStride words apart (zeroed per call)
-    uint32_t*       bits32;      // encoder: word per tile, kValid32 | bits of the tile (group g = words 64g..64g+63)
-    TileRec*        recs;        // encoder: record per tile (+1), see TileRec
-    uint64_t*       group_desc;  // granule per group: status | value (encoder and scan)
-    uint64_t*       tile_bits;   // scan kernel only: granule per scan tile, kValid | sum
+    uint8_t*        ws;          // the context's workspace (see above)
+    uint32_t        off_recs;    // encoder: byte offset of recs[] in the granule area
+    uint32_t        off_groups;  // byte offset of group_desc[] in the granule area (encoder and scan)
     uint64_t        timeout_ticks;   // s_memrealtime ticks (100 MHz)
     uint32_t        stall_tile;      // TEST HOOK: this tile's bit count is never published (~0: none); see hvlc_api.hip
     uint32_t        dbg;             // ablation flags, honoured only in -DHVLC_EXPERIMENT builds (tools/)
     uint64_t*       dbg_tl;          // per-tile timeline [tiles][8] (100 MHz ticks), -DHVLC_EXPERIMENT builds only
     uint64_t*       dbg_ws;          // per-wave time accounting [grid][8 waves][16] (shader clocks), -DHVLC_EXPERIMENT builds only
+
+    __device__ __forceinline__ const uint2* lut() const { return (const uint2*)ws; }              // {codeword (masked), length} x 256, built by k_prepare
+    __device__ __forceinline__ uint32_t* status() const { return (uint32_t*)(ws + kWsLutBytes); }  // flag word (atomic RMWs only), [1] table layout
+    __device__ __forceinline__ uint64_t* result() const { return (uint64_t*)(ws + kWsLutBytes + 8); }
+    __device__ __forceinline__ uint8_t*  gran() const { return ws + kWsHeaderBytes; }
+    // encoder: kTicketClasses counters, kTicketStride words apart (zeroed per call)
+    __device__ __forceinline__ uint32_t* tickets() const { return (uint32_t*)gran(); }
+    // encoder: word per tile, kValid32 | bits of the tile (group g = words 64g..64g+63)
+    __device__ __forceinline__ uint32_t* bits32() const { return (uint32_t*)(gran() + kWsOffBits32); }
+    // encoder: record per tile (+1)
+    __device__ __forceinline__ struct TileRec* recs() const { return (struct TileRec*)(gran() + off_recs); }
+    // granule per group: status | value (encoder and scan)
+    __device__ __forceinline__ uint64_t* group_desc() const { return (uint64_t*)(gran() + off_groups); }
+    // scan kernel only: granule per scan tile, kValid | sum
+    __device__ __forceinline__ uint64_t* tile_bits() const { return (uint64_t*)gran(); }
 };
 
 // Ablation switches for tools/ablate.py.  In the product build HVLC_DBG() is a compile-time false.
@@ -229,10 +247,10 @@ struct Spin {
         __builtin_amdgcn_s_sleep(HVLC_WAIT_SLEEP);
         if ((++n & 1023u) == 0u) {
             const uint64_t now = __builtin_amdgcn_s_memrealtime();
-            const uint32_t st  = atomicOr(p.status, 0u);     // RMW: coherent with the other workgroups' atomicOr
+            const uint32_t st  = atomicOr(p.status(), 0u);     // RMW: coherent with the other workgroups' atomicOr
             if (t0 == 0) t0 = now;
             if ((st & kFlagTimeout) || now - t0 > p.timeout_ticks) {
-                atomicOr(p.status, kFlagTimeout);
+                atomicOr(p.status(), kFlagTimeout);
                 return false;
             }
         }
@@ -459,7 +477,7 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
 
     uint64_t d = L.d;
     const bool need = (uint32_t)lane < r;
-    const uint64_t* src = p.tile_bits + (need ? tile - 1 - (uint64_t)lane : 0);
+    const uint64_t* src = p.tile_bits() + (need ? tile - 1 - (uint64_t)lane : 0);
     for (;;) {
         if (!__any(need && !(d >> 63))) break;
         if (need && !(d >> 63)) d = ld_granule(src);
@@ -468,7 +486,7 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
     }
     const uint64_t insum = WIDE ? wave_sum_u64(need ? (d & kValMask) : 0ull)
                                 : (uint64_t)wave_sum_u32(need ? (uint32_t)d : 0u);
-    if (leader && lane == 0) st_granule(&p.group_desc[g], kStAgg | ((insum + T) & kValMask));
+    if (leader && lane == 0) st_granule(&p.group_desc()[g], kStAgg | ((insum + T) & kValMask));
 
     uint64_t excl = 0;
     bool first = true;
@@ -483,7 +501,7 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
             const uint64_t xm  = __ballot((v >> 62) == 0);
             const uint64_t low = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
             if ((xm & low) == 0) break;
-            if (gi >= 0 && (v >> 62) == 0) v = ld_granule(&p.group_desc[gi]);
+            if (gi >= 0 && (v >> 62) == 0) v = ld_granule(&p.group_desc()[gi]);
             const uint64_t pm2 = __ballot((v >> 62) == 2);
             fp = pm2 ? __builtin_ctzll(pm2) : 64;
             const uint64_t xm2  = __ballot((v >> 62) == 0);
@@ -495,7 +513,7 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
         if (fp < 64) break;
     }
     const uint64_t P = excl + insum;
-    if (leader && lane == 0) st_granule(&p.group_desc[g], kStPre | ((P + T) & kValMask));
+    if (leader && lane == 0) st_granule(&p.group_desc()[g], kStPre | ((P + T) & kValMask));
     P_out = P;
     return true;
 }
@@ -547,7 +565,7 @@ __device__ __forceinline__ void store_words(const EncodeParams& p, const uint32_
 {
     // capacity: decided once per call (all arguments are wave-uniform), not per word
     if (ow + nown > p.out_cap) {
-        if (lane == 0) atomicOr(p.status, kFlagCapacity);
+        if (lane == 0) atomicOr(p.status(), kFlagCapacity);
         nown = ow < p.out_cap ? (uint32_t)(p.out_cap - ow) : 0u;
     }
     if (HVLC_DBG(p, kDbgNoStore)) return;
@@ -636,7 +654,7 @@ __device__ __forceinline__ void publish_tail(const EncodeParams& p, Smem& sm, ui
                 lds_rel(&sm.wrec[slot][last].tail, kValid32 | tail);
             }
         }
-        if (last == kDataWaves - 1) st_word(&p.recs[(uint64_t)tile + 1].tail, kValid32 | tail);
+        if (last == kDataWaves - 1) st_word(&p.recs()[(uint64_t)tile + 1].tail, kValid32 | tail);
     }
     if (LATE) wake_workgroup();                       // the next wave may be sleeping on it (an early tail is never waited for)
 }
@@ -678,7 +696,7 @@ __device__ __forceinline__ bool store_part(const EncodeParams& p, Smem& sm, uint
     }
     const bool last = (tile == (uint32_t)(p.num_tiles - 1)) && wave == kDataWaves - 1;
     if (last && lane == 0) {
-        p.result[0] = G + T;
+        p.result()[0] = G + T;
         if (p.total_bits) *p.total_bits = G + T;
     }
     // the last part of the stream also stores the open word, zero padded, and the zero word cpu_vlc_encode leaves
@@ -738,7 +756,7 @@ __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint3
         G += Tq;
     }
     if (last_part && lane == 0) {
-        p.result[0] = G;
+        p.result()[0] = G;
         if (p.total_bits) *p.total_bits = G;
     }
     publish_tail<true>(p, sm, slot, wave, tile, carry, lane);
@@ -892,7 +910,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             if (lane == 0) {
                 sm.ts[slot].arrive = 0u;
                 (void)__hip_atomic_fetch_max(&sm.n_bits_pub, c.m_packed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (cur != p.stall_tile) st_word(&p.bits32[cur], kValid32 | Ttile);
+                if (cur != p.stall_tile) st_word(&p.bits32()[cur], kValid32 | Ttile);
             }
             TL(p, cur, 0, lane == 0);
         }
@@ -985,7 +1003,7 @@ static_assert(kMaxPoll < kSlots, "a polled tile's slot must still belong to it")
 template <bool WINDOW>
 __device__ __forceinline__ uint64_t poll_round(const EncodeParams& p, uint32_t rec_off, const void* w, int lane)
 {
-    const char* src = (const char*)p.recs + rec_off;
+    const char* src = (const char*)p.recs() + rec_off;
     if (WINDOW && lane >= 32) src = (const char*)w + (uint32_t)(lane - 32) * 8u;
     uint64_t v = 0;
     if (lane < 2 * kMaxPoll || (WINDOW && lane >= 32 && lane < 32 + kWindow)) v = ld_granule((const uint64_t*)src);
@@ -1009,7 +1027,7 @@ struct LeaderDuty {
 __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& sm, int lane)
 {
     // lanes 2q, 2q+1 poll the record of the tile in poll slot q (workgroup-local tile n uses slot n % kMaxPoll):
-    // byte offset from p.recs of the 8 bytes this lane reads (record 0 until a slot is started)
+    // byte offset from p.recs() of the 8 bytes this lane reads (record 0 until a slot is started)
     uint32_t rec_off = (uint32_t)(lane & 1) * 8u;
     uint32_t n_started = 0, n_done = 0; // tiles whose record is being polled / handed to the data waves
     uint32_t n_duty = 0;                // tiles already checked for the group-leader role
@@ -1052,11 +1070,11 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
         //     tiles in flight and, for a leader, 16 group granules, in one vector load
         uint32_t bv = kValid32;
         if (d.active && !d.have_bits && (uint32_t)lane < d.n)
-            bv = __hip_atomic_load(&p.bits32[(uint64_t)d.g * kGroupTiles + (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bv = __hip_atomic_load(&p.bits32()[(uint64_t)d.g * kGroupTiles + (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint64_t pv;                     // lanes 0-11: the records of the tiles in flight; lanes 32-47: the leader's window
         if (d.active && !d.win_done) {
             const int32_t c0 = d.j & ~(kWindow - 1);
-            pv = poll_round<true>(p, rec_off, p.group_desc + c0, lane);
+            pv = poll_round<true>(p, rec_off, p.group_desc() + c0, lane);
             bool stop = false;
 #pragma unroll
             for (int i = kWindow - 1; i >= 0; --i) {
@@ -1085,7 +1103,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
         if (n_final == ~0u && !tix_inflight && n_tix < lds_rlx(&sm.n_bits_pub) + (uint32_t)kTixAhead &&
             n_tix - n_duty < (uint32_t)(kTq - 1)) {                 // (a tile number stays queued until the duty scan has seen it)
             if (lane == 0)
-                tix_k = __hip_atomic_fetch_add(&p.tickets[cls * (uint32_t)kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tix_k = __hip_atomic_fetch_add(&p.tickets()[cls * (uint32_t)kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             tix_inflight = true;
         }
 
@@ -1132,13 +1150,13 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
                 d.have_bits = true;
                 progress    = true;
                 TL(p, (uint64_t)d.g * kGroupTiles + d.n - 1u, 2, lane == 0);
-                if (lane == 0 && !d.win_done) st_granule(&p.group_desc[d.g], kStAgg | (uint64_t)d.A);
+                if (lane == 0 && !d.win_done) st_granule(&p.group_desc()[d.g], kStAgg | (uint64_t)d.A);
             }
         }
         if (d.active && d.have_bits && d.win_done) {
-            if (lane == 0) st_granule(&p.group_desc[d.g], kStPre | (d.E + (uint64_t)d.A));   // later leaders wait for this
+            if (lane == 0) st_granule(&p.group_desc()[d.g], kStPre | (d.E + (uint64_t)d.A));   // later leaders wait for this
             if ((uint32_t)lane < d.n)
-                st_granule(&p.recs[(uint64_t)d.g * kGroupTiles + (uint32_t)lane].P, kValid | (d.E + (uint64_t)d.excl_in));
+                st_granule(&p.recs()[(uint64_t)d.g * kGroupTiles + (uint32_t)lane].P, kValid | (d.E + (uint64_t)d.excl_in));
             TL(p, (uint64_t)d.g * kGroupTiles + d.n - 1u, 3, lane == 0);
             d.active = false;
             progress = true;
@@ -1176,10 +1194,10 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             if (n_started == n_done && !d.active && !tix_inflight) __builtin_amdgcn_s_sleep(4);   // nothing in flight: wait for the data waves
             if ((++rounds & 255u) == 0u) {
                 const uint64_t now = __builtin_amdgcn_s_memrealtime();
-                const uint32_t st  = atomicOr(p.status, 0u);  // RMW: coherent with the other workgroups' atomicOr
+                const uint32_t st  = atomicOr(p.status(), 0u);  // RMW: coherent with the other workgroups' atomicOr
                 if (t_progress == 0) t_progress = now;
                 if ((st & kFlagTimeout) || now - t_progress > p.timeout_ticks) {
-                    atomicOr(p.status, kFlagTimeout);
+                    atomicOr(p.status(), kFlagTimeout);
                     if (lane == 0) __hip_atomic_store(&sm.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     return;
                 }
@@ -1210,11 +1228,11 @@ k_encode(EncodeParams p)
     // lut_at() addresses the table absolutely: the workgroup's LDS object must start at LDS address 0
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     if ((uint32_t)reinterpret_cast<uintptr_t>((lds_byte*)hvlc_smem_raw) != 0u) {
-        if (tid == 0) atomicOr(p.status, kFlagLayout);
+        if (tid == 0) atomicOr(p.status(), kFlagLayout);
         return;
     }
-    const bool permuted = uni(p.status[1]) != 0u;     // table layout chosen by k_prepare
-    if (tid < 256) sm.lut[permuted ? lut_slot((uint32_t)tid) : (uint32_t)tid] = p.lut[tid];
+    const bool permuted = uni(p.status()[1]) != 0u;     // table layout chosen by k_prepare
+    if (tid < 256) sm.lut[permuted ? lut_slot((uint32_t)tid) : (uint32_t)tid] = p.lut()[tid];
     {   // everything behind the table starts as zero: rings, records, counters
         uint4* z = reinterpret_cast<uint4*>(&sm.ring[0][0]);
         const uint32_t nvec = (uint32_t)((sizeof(Smem) - sizeof(sm.lut)) / 16u);
@@ -1351,7 +1369,7 @@ __global__ void __launch_bounds__(kThreads) k_exclusive_scan(const uint32_t* in,
         const uint64_t w0 = wtot[0], w1 = wtot[1], w2 = wtot[2], w3 = wtot[3];
         const uint64_t T = w0 + w1 + w2 + w3;
         const uint64_t wavebase = wave == 0 ? 0ull : wave == 1 ? w0 : wave == 2 ? w0 + w1 : w0 + w1 + w2;
-        if (tid == 0 && tile != (uint64_t)p.stall_tile) st_granule(&p.tile_bits[tile], kValid | (T & kValMask));   // (stall_tile: test hook)
+        if (tid == 0 && tile != (uint64_t)p.stall_tile) st_granule(&p.tile_bits()[tile], kValid | (T & kValMask));   // (stall_tile: test hook)
         if (wave == 0) {
             uint64_t P = 0;
             const bool ok = lookback<true>(p, tile, T, lane, LbRegs(), P);
@@ -1362,7 +1380,7 @@ __global__ void __launch_bounds__(kThreads) k_exclusive_scan(const uint32_t* in,
         uint64_t run = s_prefix + wavebase + (incl - sum);
 #pragma unroll
         for (int k = 0; k < 16; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
-        if (tile == p.num_tiles - 1 && tid == kThreads - 1) { p.result[0] = run; if (total) *total = run; }
+        if (tile == p.num_tiles - 1 && tid == kThreads - 1) { p.result()[0] = run; if (total) *total = run; }
     }
 }
 

@@ -49,11 +49,24 @@ def build(force=False, verbose=False):
         newest = max(os.path.getmtime(p) for p in DEPS)
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
+    staged = LIB_PATH + ".new"
     cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB_PATH] + SRC
+           "-o", staged] + SRC
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=HERE)
+    # Build gate: no memory instruction may take its address from an SGPR that a VALU instruction (a spill reload,
+    # v_readfirstlane) wrote a few wait states earlier -- that sequence read a stale register on MI355X (build_check.py).
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hvlc_build_check", os.path.join(HERE, "build_check.py"))
+    build_check = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(build_check)
+    found = build_check.check(staged)
+    if found:
+        os.remove(staged)
+        raise RuntimeError("libhvlc.so refused, VALU-written SGPR feeds a memory address:\n" +
+                           "\n".join(f"  {k}: `{i}` reads {r} {d} wait states after `{w}`" for k, i, r, d, w in found))
+    os.replace(staged, LIB_PATH)
     return LIB_PATH
 
 

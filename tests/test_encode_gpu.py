@@ -550,6 +550,26 @@ def test_general_path_large(enc):
     _check_windows(enc, d_in, out, offs, bits, cw, cl, hist, 8, np.random.default_rng(2))
 
 
+@pytest.mark.parametrize("kind,mib", [("any", 32), ("long", 32), ("any", 96)])
+def test_every_part_on_the_slow_path_beyond_one_tile_per_workgroup(kind, mib):
+    """Random bytes under tables with codes up to 31 bits: no part fits its wave's ring, every part takes the chained
+    slow path and the scouts poll for ~100 ms (0.36 GB/s: the chain is serial).  With more tiles than workgroups this
+    was the input that faulted in round 2 (a spilled pointer reloaded right in front of the polling load, see
+    huffman-gpu_amd/build_check.py); full word-for-word compare."""
+    rng = np.random.default_rng(3)
+    n = mib << 20
+    cw, cl = random_table(rng, kind)
+    x = rng.integers(0, 1 << 32, n // 4, dtype=np.uint64).astype(np.uint32)
+    e = hvlc.Encoder(0, n // 4)
+    assert n // (28 << 10) > e.launch_info()["grid_blocks"], "needs workgroups that draw a second tile"
+    d_in = torch.from_numpy(x.view(np.int32)).cuda()
+    out, offs, bits = e.encode(d_in, e.table_to_device(cw, cl), max_len=int(cl.max()))
+    bad, first = O.compare_stream_mt(x, cw, cl, out[: bits // 32 + 1].cpu().numpy().view(np.uint32),
+                                     offs.cpu().numpy().view(np.uint64), bits, chunk_segments=512)
+    assert bad == 0, (bad, first)
+    e.close()
+
+
 # ---------------------------------------------------------------------------------------------------------
 # SURVEY.md section 8(f) "next" rows: seam merge (#1) and decoder (#3)
 # ---------------------------------------------------------------------------------------------------------
