@@ -582,6 +582,13 @@ __device__ __forceinline__ void zero_words(uint32_t* base, uint32_t n_vec4, int 
     for (uint32_t i = (uint32_t)lane; i < n_vec4; i += 64u) z[i] = make_uint4(0, 0, 0, 0);
 }
 
+// The lane number, recomputed where it is called (two VALU instructions) instead of kept in a register from the prologue.
+__device__ __forceinline__ int lane_id_fresh()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 // LDS words shared between the waves of a workgroup: relaxed / acquire / release at WORKGROUP scope (LDS
 // operations of one wave complete in order; the scopes only keep the compiler from reordering them).
 __device__ __forceinline__ uint32_t lds_acq(const uint32_t* p) { return uni(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
@@ -711,18 +718,55 @@ __device__ __forceinline__ bool store_part(const EncodeParams& p, Smem& sm, uint
     return true;
 }
 
+// The tail (last 31 stream bits) of a FULL part that will take the slow path, computed at pack time from its last
+// segment alone -- in registers: every lane folds its 16 symbols into (last <=31 bits, their count), a wave scan with
+// the same operator joins the lanes.  Published like the early tail of a packed part, so that nothing behind a slow
+// part waits for it to be stored: a stream of slow parts only (a table that EXPANDS its input beyond ~13 bits per
+// byte) otherwise runs one part at a time, each waiting for the tail of the one in front.  False: the last segment
+// holds fewer than 31 bits (zero-length codes), the tail follows when the part is stored.
+__device__ __forceinline__ bool publish_slow_tail_early(const EncodeParams& p, Smem& sm, uint32_t slot, int wave, uint32_t tile,
+                                                        int lane, bool permuted)
+{
+    const uint64_t seg = (uint64_t)tile * kSegsPerTile + (uint64_t)(wave * kRows + (kRows - 1));
+    const uint4 v = ((const uint4*)p.in)[seg * (kSegWords / 4u) + (uint64_t)lane];
+    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+    uint32_t tl = 0, ln = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t h = hash4_if(w[k], permuted);
+#pragma unroll
+        for (int b = 3; b >= 0; --b) {
+            const uint2 e = sm.lut[(h >> (8 * b)) & 255u];             // lengths <= 31: the shift is defined
+            tl = ((tl << e.y) | e.x) & 0x7fffffffu;
+            ln = min(31u, ln + e.y);
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {                                 // inclusive scan: (A, B) -> B behind A
+        const uint32_t tl_a = (uint32_t)__shfl_up((int)tl, d), ln_a = (uint32_t)__shfl_up((int)ln, d);
+        if (lane >= d && ln < 31u) {
+            tl = ((tl_a << ln) | tl) & 0x7fffffffu;
+            ln = min(31u, ln_a + ln);
+        }
+    }
+    const uint32_t tail = (uint32_t)__builtin_amdgcn_readlane((int)tl, 63);
+    if ((uint32_t)__builtin_amdgcn_readlane((int)ln, 63) < 31u) return false;
+    publish_tail<false>(p, sm, slot, wave, tile, tail, lane);
+    wake_workgroup();                                                  // unlike a packed part's, this tail may be waited for already
+    return true;
+}
+
 // Slow path for ONE wave's part of a tile: the part does not fit the wave's (empty) ring (more than ~13 bits per
 // symbol), or the tile is the one the input ends in.  Runs with the ring drained and the tile resolved, segment by
 // segment: the segment is re-read (valid words only), packed two symbols (<=62 bits) per put_bits64 into the ring
 // taken as one buffer, funnel-shifted and stored; the carry runs through the segments exactly as it runs through
-// parts.  Leaves the ring zeroed.
+// parts.  Leaves the ring zeroed.  `tail_published`: publish_slow_tail_early has done its work.
 __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint32_t* ring, uint32_t j, uint32_t tile,
-                                          int wave, int lane, bool permuted)
+                                          int wave, int lane, bool permuted, bool tail_published)
 {
     const uint32_t slot = j % kSlots;
     uint64_t G = uni64(sm.ts[slot].prefix) + (uint64_t)uni(sm.wrec[slot][wave].base);
-    uint32_t carry;
-    if (!pred_tail_of(p, sm, slot, wave, lane, carry)) return false;
+    uint32_t carry = 0;
     const bool last_part = (tile == (uint32_t)(p.num_tiles - 1)) && wave == kDataWaves - 1;
     const uint32_t* in32 = (const uint32_t*)p.in;
 #pragma unroll 1
@@ -743,9 +787,10 @@ __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint3
             }
         const uint32_t incl = wave_incl_scan(t);
         const uint32_t Tq = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        put_row_pairs(ring + 1, incl - t, w, n, sm.lut, permuted);
+        if (r == 0 && !pred_tail_of(p, sm, slot, wave, lane, carry)) return false;     // first needed here, behind the packing
         if (p.offsets && lane == 0 && seg < p.num_segs) p.offsets[seg] = G;
         if (lane == 0) ring[0] = carry;
-        put_row_pairs(ring + 1, incl - t, w, n, sm.lut, permuted);
         const uint32_t s = (uint32_t)G & 31u;
         const bool lastq = last_part && r == kRows - 1;
         uint32_t nown = (s + Tq) >> 5;
@@ -759,7 +804,7 @@ __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint3
         p.result()[0] = G;
         if (p.total_bits) *p.total_bits = G;
     }
-    publish_tail<true>(p, sm, slot, wave, tile, carry, lane);
+    if (!tail_published) publish_tail<true>(p, sm, slot, wave, tile, carry, lane);
     return true;
 }
 
@@ -903,9 +948,12 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         old = uni(old);
         if ((old >> 24) == (uint32_t)(kDataWaves - 1)) {
             // last to arrive: every part's base, the tile's bit count (what other workgroups wait for), slot counter reset
-            const uint32_t b    = lane < kDataWaves ? sm.wrec[slot][lane].bits : 0u;
+            // (the lane number is taken afresh: kept live from the prologue, the per-lane record address it feeds was
+            // spilled to scratch and reloaded right here, on the path other workgroups wait for)
+            const int ln = lane_id_fresh();
+            const uint32_t b    = ln < kDataWaves ? sm.wrec[slot][ln].bits : 0u;
             const uint32_t incl = wave_incl_scan(b);
-            if (lane < kDataWaves) sm.wrec[slot][lane].base = incl - b;
+            if (ln < kDataWaves) sm.wrec[slot][ln].base = incl - b;
             const uint32_t Ttile = (uint32_t)__builtin_amdgcn_readlane((int)incl, kDataWaves - 1);
             if (lane == 0) {
                 sm.ts[slot].arrive = 0u;
@@ -956,7 +1004,9 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             ++c.m_packed;
             WS_LAP(kWsPack); WS_COUNT(kWsTiles);
         } else {
-            // slow path: drain the ring, wait for this tile's offset, store the part directly
+            // slow path: the tail first if the part allows, then drain the ring, wait for this tile's offset, store the
+            // part directly
+            const bool tail_out = full && publish_slow_tail_early(p, sm, slot, wave, cur, lane, permuted);
             ++c.m_packed;
             WaveWait w;
             while (c.m_stored + 1u < c.m_packed) {
@@ -966,7 +1016,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             }
             while (lds_acq(&sm.n_resolved) < c.m_packed)
                 if (!w.step(p, sm, lane)) return;
-            if (!slow_part(p, sm, ring, c.m_packed - 1u, cur, wave, lane, permuted)) return;
+            if (!slow_part(p, sm, ring, c.m_packed - 1u, cur, wave, lane, permuted, tail_out)) return;
             ++c.m_stored;
             if (lane == 0) lds_rel(&sm.stored[wave], c.m_stored);
             c.head = 0;

@@ -552,10 +552,11 @@ def test_general_path_large(enc):
 
 @pytest.mark.parametrize("kind,mib", [("any", 32), ("long", 32), ("any", 96)])
 def test_every_part_on_the_slow_path_beyond_one_tile_per_workgroup(kind, mib):
-    """Random bytes under tables with codes up to 31 bits: no part fits its wave's ring, every part takes the chained
-    slow path and the scouts poll for ~100 ms (0.36 GB/s: the chain is serial).  With more tiles than workgroups this
-    was the input that faulted in round 2 (a spilled pointer reloaded right in front of the polling load, see
-    huffman-gpu_amd/build_check.py); full word-for-word compare."""
+    """Random bytes under tables with codes up to 31 bits: no part fits its wave's ring, every part takes the slow
+    path (tails published at pack time from the last segment, parts stored segment by segment).  With more tiles than
+    workgroups this was the input that faulted in round 2 -- then at 0.36 GB/s, with the scouts polling for ~100 ms (a
+    spilled pointer reloaded right in front of the polling load, see huffman-gpu_amd/build_check.py); full
+    word-for-word compare."""
     rng = np.random.default_rng(3)
     n = mib << 20
     cw, cl = random_table(rng, kind)
