@@ -10,7 +10,7 @@ Workload (config.workload): the north-star / BASELINE config 5 shard -- a 4 GiB 
 H~2.2 byte stream PER GPU (weak scaling; at N ranks the job is the 4N GiB stream of
 SURVEY.md section 8(d), shard g drawing from index g*2^31, seed 0x5EED0005), encoded with
 the Huffman table of the job's global histogram.  A "step" is one whole pass of the hot
-path over the rank's shard: hvlc_encode (k_prepare + the fused k_encode) and, for N>1,
+path over the rank's shard: hvlc_encode (ONE launch of the fused k_encode) and, for N>1,
 the stitch (hvlc.stitch): ONE RCCL all-gather of the per-shard bit totals + the device-side
 rebase of the segment offsets.  Inputs are resident in HBM before the timed region; nothing
 is skipped.

@@ -9,16 +9,17 @@ Scans the gfx950 code object for the sequence that faulted in round 2:
 
 On MI355X the load was seen (rarely: once per ~10^8 executions, in the scouts' polling loop) to use the OLD value of
 s63: "Memory access fault ... on address 0xffff1ca03000" = {new low half, stale high half = -1}.  The same code with
-the s_nop lengthened never faulted (profiles/README.md, "the readlane hazard").  So this build keeps VALU-written SGPRs
-away from VMEM address operands altogether, and this script proves it for the binary that ships:
+the s_nop lengthened never faulted (profiles/README.md, "the readlane hazard").  hazard_pass.py therefore puts a SALU
+copy of the register onto itself (interlocked in hardware) in front of every such memory instruction, on any path; this
+script is the independent check of the binary that ships:
 
     python huffman-gpu_amd/build_check.py [libhvlc.so] [--min-wait-states 12]
 
-exits 1 and lists every VMEM (or SMEM) instruction that reads an SGPR some VALU instruction wrote fewer than
---min-wait-states wait states earlier (straight-line distance in the disassembly; a label in between does not reset it,
-which is conservative for fall-through and blind to hazards across a taken branch -- the compiler's own pass covers
-those with its 5 states).  hvlc.build() refuses a library that fails it; tests/test_build_check.py pins the scanner
-itself on the sequence above."""
+exits 1 and lists every VMEM instruction that reads an SGPR some VALU instruction wrote fewer than --min-wait-states wait
+states earlier with no SALU write of it in between (straight-line distance in the disassembly; a label in between does
+not reset it, which is conservative for fall-through; paths through taken branches are hazard_pass.py's data-flow
+analysis).  SMEM addresses are interlocked like SALU reads and not listed.  hvlc.build() refuses a library that fails;
+tests/test_build_check.py pins the scanner and the pass on the sequence above."""
 import argparse
 import os
 import re
@@ -79,7 +80,7 @@ def scan(disassembly, min_ws):
         if not ins:
             continue
         mnem, _, ops = ins.partition(" ")
-        if mnem.startswith(VMEM_PREFIX) or mnem.startswith(SMEM_PREFIX):
+        if mnem.startswith(VMEM_PREFIX):      # (SMEM addresses are interlocked in hardware like any SALU read)
             for r in sorted(sregs(ops)):
                 if r in last_write and clock - last_write[r][0] - 1 < min_ws:
                     findings.append((kernel, ins, "s%d" % r, clock - last_write[r][0] - 1, last_write[r][1]))

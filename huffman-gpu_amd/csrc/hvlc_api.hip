@@ -35,8 +35,11 @@ struct hvlc_ctx {
     int       blocks_per_cu = 0;
     int       last_hip      = 0;
     int       last_grid     = 0;
-    uint8_t*  ws            = nullptr;   // [lut 2 KiB][status/result 64 B][granules...]
-    uint64_t  granule_bytes = 0;         // capacity of the granule region
+    uint8_t*  ws            = nullptr;   // [control block 64 B][granule area, half 0][half 1]  (EncodeParams, hvlc_device.hip.h)
+    uint64_t  half_bytes    = 0;         // capacity of one half
+    uint8_t*  scan_ws       = nullptr;   // hvlc_exclusive_scan's own granule area
+    uint64_t  scan_bytes    = 0;
+    int       last_op       = 0;         // what hvlc_finish reports on: 0 nothing yet / an empty encode, 1 encode, 2 scan
     uint64_t  timeout_ticks = 200000000ull;   // 2 s of the 100 MHz real-time counter
     int       scan_blocks_per_cu = 0;        // k_exclusive_scan occupancy on this device (picked on first use)
     bool      decode_lds_set = false;        // k_decode's dynamic LDS size registered on this device
@@ -44,7 +47,7 @@ struct hvlc_ctx {
     uint32_t  hook_stall_tile = ~0u;
     int       hook_force_grid = 0;
     // pinned host mirror for hvlc_finish
-    uint32_t* h_status      = nullptr;   // [0] flags, [2..3] total bits
+    uint32_t* h_status      = nullptr;   // copy of the control block
     // optional event pairs around k_encode (hvlc_profile_begin / _collect)
     hipEvent_t* ev          = nullptr;
     int       ev_cap        = 0;
@@ -53,9 +56,7 @@ struct hvlc_ctx {
 
 namespace {
 
-constexpr uint64_t kLutBytes    = kWsLutBytes;      // the layout of the workspace is the device header's (EncodeParams)
-constexpr uint64_t kStatusBytes = kWsStatusBytes;
-constexpr uint64_t kHeaderBytes = kWsHeaderBytes;
+// the layout of the workspace is the device header's (EncodeParams)
 static_assert(kWsOffBits32 == kTicketClasses * kTicketStride * 4, "ticket counters sit in front of bits32");
 
 #define HVLC_HIP(ctx, call)                                   \
@@ -81,54 +82,63 @@ hipError_t launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, h
     return hipLaunchKernel((const void*)kernel, grid, block, ptrs, lds, s);
 }
 
-// workspace behind the header, for an encoder call of `tiles` tiles (offsets in bytes):
-//   tickets [8 x 128 B] | bits32 [round_up(tiles, 64)] | recs [tiles + 1] | group_desc [groups, padded for the leaders' 16-granule window]
-// k_exclusive_scan reuses the same area as  tile_bits [tiles] | group_desc [groups]  (8 bytes each).
-struct Layout { uint64_t off_tickets, off_bits32, off_recs, off_groups, bytes, scan_off_groups, scan_bytes; };
+// One half of the granule area for an encoder call of `tiles` tiles (offsets in bytes):
+//   tickets [64 x 128 B] | bits32 [round_up(tiles, 64)] | recs [tiles + 1] | group_desc [groups, padded for the leaders' 16-granule window]
+// k_exclusive_scan has its own area:  tile_bits [tiles] | group_desc [groups]  (8 bytes each).
+struct Layout { uint64_t off_bits32, off_recs, off_groups, bytes, scan_off_groups, scan_bytes; };
 inline Layout layout_for(uint64_t tiles)
 {
     Layout l;
     const uint64_t groups = (tiles + kGroupTiles - 1) / kGroupTiles;
-    l.off_tickets = 0;
-    l.off_bits32 = (uint64_t)kTicketClasses * kTicketStride * 4;
+    l.off_bits32 = kWsOffBits32;
     l.off_recs   = l.off_bits32 + round_up(round_up(tiles, kGroupTiles) * 4, 64);
     l.off_groups = l.off_recs + round_up((tiles + 1) * sizeof(TileRec), 64);
-    l.bytes      = l.off_groups + (round_up(groups, kWindow) + kWindow) * 8;
+    l.bytes      = round_up(l.off_groups + (round_up(groups, kWindow) + kWindow) * 8, 64);
     l.scan_off_groups = round_up(tiles * 8, 64);
-    l.scan_bytes = l.scan_off_groups + (groups + 1) * 8;
-    if (l.bytes < l.scan_bytes) l.bytes = round_up(l.scan_bytes, 64);
+    l.scan_bytes = round_up(l.scan_off_groups + (groups + 1) * 8, 64);
     return l;
+}
+
+int zero_area(hvlc_ctx* c, uint8_t* area, uint64_t bytes, uint32_t* status, uint64_t* result, hipStream_t s)
+{
+    const uint64_t vecs = bytes / 16;
+    int grid = (int)((vecs + kThreads - 1) / kThreads);
+    if (grid < 1) grid = 1;
+    if (grid > 2048) grid = 2048;
+    HVLC_HIP(c, launch(k_zero, dim3(grid), dim3(kThreads), 0, s, (uint4*)area, vecs, status, result));
+    return HVLC_OK;
 }
 
 int ensure_workspace(hvlc_ctx* c, uint64_t tiles)
 {
     const Layout l = layout_for(tiles);
-    if (c->ws && l.bytes <= c->granule_bytes) return HVLC_OK;
+    if (c->ws && l.bytes <= c->half_bytes) return HVLC_OK;
     // growing is not capture-safe; size the context for the largest input up front to avoid it
     if (c->ws) { HVLC_HIP(c, hipDeviceSynchronize()); HVLC_HIP(c, hipFree(c->ws)); c->ws = nullptr; }
     const uint64_t want = round_up(l.bytes, 4096);
-    HVLC_HIP(c, hipMalloc((void**)&c->ws, kHeaderBytes + want));
-    c->granule_bytes = want;
+    if (want > 0xfffff000ull) return HVLC_ERR_ARG;            // 32-bit byte offsets inside a half
+    HVLC_HIP(c, hipMalloc((void**)&c->ws, kWsCtlBytes + 2 * want));
+    c->half_bytes = want;
+    // everything zero: both halves, both status words, the call counter (kernels, not a memset: the status words only
+    // ever see atomic RMWs).  Every encode then leaves the half the NEXT one uses zeroed (k_encode's prologue).
+    int rc = zero_area(c, c->ws, kWsCtlBytes + 2 * want, (uint32_t*)c->ws, nullptr, nullptr);
+    if (rc == HVLC_OK) HVLC_HIP(c, hipDeviceSynchronize());
+    c->last_op = 0;
+    return rc;
+}
+
+int ensure_scan_workspace(hvlc_ctx* c, uint64_t tiles)
+{
+    const Layout l = layout_for(tiles);
+    if (c->scan_ws && l.scan_bytes <= c->scan_bytes) return HVLC_OK;
+    if (c->scan_ws) { HVLC_HIP(c, hipDeviceSynchronize()); HVLC_HIP(c, hipFree(c->scan_ws)); c->scan_ws = nullptr; }
+    const uint64_t want = round_up(l.scan_bytes, 4096);
+    HVLC_HIP(c, hipMalloc((void**)&c->scan_ws, want));
+    c->scan_bytes = want;
     return HVLC_OK;
 }
 
-inline uint2*    ws_lut(hvlc_ctx* c)    { return (uint2*)c->ws; }
-inline uint32_t* ws_status(hvlc_ctx* c) { return (uint32_t*)(c->ws + kLutBytes); }
-inline uint64_t* ws_result(hvlc_ctx* c) { return (uint64_t*)(c->ws + kLutBytes + 8); }
-inline uint8_t*  ws_gran(hvlc_ctx* c)   { return c->ws + kHeaderBytes; }
-
-void fill_granule_ptrs(hvlc_ctx* c, uint64_t tiles, EncodeParams& p, bool scan)
-{
-    const Layout l = layout_for(tiles);
-    p.ws = c->ws;                       // offsets fit 32 bits: 16 bytes of records per 28 KiB tile
-    if (scan) {
-        p.off_groups = (uint32_t)l.scan_off_groups;
-    } else {
-        p.off_recs   = (uint32_t)l.off_recs;
-        p.off_groups = (uint32_t)l.off_groups;
-    }
-    p.timeout_ticks = c->timeout_ticks;
-}
+inline uint32_t* ws_ctl(hvlc_ctx* c) { return (uint32_t*)c->ws; }
 
 int env_int(const char* name, int dflt)
 {
@@ -244,6 +254,7 @@ int hvlc_destroy(hvlc_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     if (c->ws) (void)hipFree(c->ws);
+    if (c->scan_ws) (void)hipFree(c->scan_ws);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->ev) { for (int i = 0; i < 2 * c->ev_cap; ++i) (void)hipEventDestroy(c->ev[i]); delete[] c->ev; }
     delete c;
@@ -289,13 +300,24 @@ int hvlc_encode(hvlc_ctx* c,
     int rc = ensure_workspace(c, tiles);
     if (rc != HVLC_OK) return rc;
 
+    if (tiles == 0) {                                         // the empty stream: one zero word (cpuencode.cpp:17)
+        HVLC_HIP(c, launch(k_encode_empty, dim3(1), dim3(1), 0, s, d_out_bits, d_total_bits));
+        c->last_grid = 0;
+        c->last_op = 0;
+        return HVLC_OK;
+    }
+    const Layout l = layout_for(tiles);
     EncodeParams p;
     memset(&p, 0, sizeof(p));
     p.in = (const uint4*)d_in;  p.num_words = num_words;  p.num_tiles = tiles;
     p.num_segs = hvlc_num_segments(num_words);
+    p.cw = d_codewords;  p.cl = d_codewordlens;
     p.out = d_out_bits;  p.out_cap = out_capacity_words;
     p.offsets = d_out_offsets;  p.total_bits = d_total_bits;
-    fill_granule_ptrs(c, tiles, p, false);
+    p.ws = c->ws;  p.gran0 = c->ws + kWsCtlBytes;
+    p.half_bytes = (uint32_t)c->half_bytes;  p.used_bytes = (uint32_t)l.bytes;
+    p.off_recs = (uint32_t)l.off_recs;  p.off_groups = (uint32_t)l.off_groups;
+    p.timeout_ticks = c->timeout_ticks;
     p.stall_tile = c->hook_stall_tile;                        // ~0 unless a test set it (hvlc_test_hook)
 #ifdef HVLC_EXPERIMENT
     p.dbg = (uint32_t)env_int("HVLC_DBG", 0);
@@ -303,18 +325,8 @@ int hvlc_encode(hvlc_ctx* c,
     p.dbg_ws = g_dbg_ws;
 #endif
 
-    const Layout l = layout_for(tiles);
-    const uint64_t vecs = l.bytes / 16;
-    int pgrid = (int)((vecs + kThreads - 1) / kThreads);
-    if (pgrid < 1) pgrid = 1;
-    if (pgrid > 2048) pgrid = 2048;
-    HVLC_HIP(c, launch(k_prepare, dim3(pgrid), dim3(kThreads), 0, s,
-                       d_codewords, d_codewordlens, ws_lut(c), ws_status(c), ws_result(c),
-                       (uint4*)ws_gran(c), vecs, l.off_recs / 16, d_out_bits, out_capacity_words, d_total_bits,
-                       tiles == 0 ? 1 : 0));
-    if (tiles == 0) { c->last_grid = 0; return HVLC_OK; }
-
     c->last_grid = (int)grid;
+    c->last_op = 1;
     const bool prof = c->ev && c->ev_used < c->ev_cap;
     if (prof) HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used], s));
     HVLC_HIP(c, launch(k_encode, dim3((unsigned)grid), dim3(kEncThreads), sizeof(Smem), s, p));
@@ -372,11 +384,17 @@ int hvlc_finish(hvlc_ctx* c, void* stream, uint64_t* total_bits)
     if (!c) return HVLC_ERR_ARG;
     HVLC_HIP(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    HVLC_HIP(c, hipMemcpyAsync(c->h_status, ws_status(c), 16, hipMemcpyDeviceToHost, s));
+    HVLC_HIP(c, hipMemcpyAsync(c->h_status, c->ws, kWsCtlBytes, hipMemcpyDeviceToHost, s));
     HVLC_HIP(c, hipStreamSynchronize(s));
-    const uint32_t flags = c->h_status[0];
-    uint64_t bits;
-    memcpy(&bits, &c->h_status[2], 8);
+    uint32_t flags = 0;
+    uint64_t bits = 0;
+    if (c->last_op == 1) {              // the last encode: the status word of the half it ran in (the call counter has moved on)
+        flags = c->h_status[(c->h_status[kCtlCalls] + 1u) & 1u];
+        memcpy(&bits, &c->h_status[2 * kCtlResult64], 8);
+    } else if (c->last_op == 2) {
+        flags = c->h_status[kCtlScanStatus];
+        memcpy(&bits, &c->h_status[2 * kCtlScanResult64], 8);
+    }
     if (total_bits) *total_bits = bits;
     if (flags & kFlagLayout)   return HVLC_ERR_HIP;      // LDS layout assumption broken: a build problem, never data
     if (flags & kFlagTimeout)  return HVLC_ERR_TIMEOUT;
@@ -453,20 +471,20 @@ int hvlc_exclusive_scan(hvlc_ctx* c, const uint32_t* d_counts, uint64_t n,
         if (d_total) HVLC_HIP(c, hipMemsetAsync(d_total, 0, 8, s));
         return HVLC_OK;
     }
-    int rc = ensure_workspace(c, tiles);
+    int rc = ensure_scan_workspace(c, tiles);
     if (rc != HVLC_OK) return rc;
+    const Layout l = layout_for(tiles);
     EncodeParams p;
     memset(&p, 0, sizeof(p));
     p.num_tiles = tiles;
     p.stall_tile = c->hook_stall_tile;                        // ~0 unless a test set it (hvlc_test_hook)
-    fill_granule_ptrs(c, tiles, p, true);
-    const Layout l = layout_for(tiles);
-    // granules zeroed and the status word reset by a kernel: the status word is only ever touched with atomic
-    // RMWs (k_prepare's comment), never by a memset
-    const uint64_t vecs = round_up(l.scan_bytes, 16) / 16;
-    int pgrid = (int)((vecs + kThreads - 1) / kThreads);
-    if (pgrid > 2048) pgrid = 2048;
-    HVLC_HIP(c, launch(k_scan_reset, dim3(pgrid), dim3(kThreads), 0, s, (uint4*)ws_gran(c), vecs, ws_status(c), ws_result(c)));
+    p.ws = c->ws;  p.gran0 = c->scan_ws;  p.scan = 1u;
+    p.off_groups = (uint32_t)l.scan_off_groups;
+    p.timeout_ticks = c->timeout_ticks;
+    // granules zeroed and the status word reset by a kernel: the status words are only ever touched with atomic RMWs
+    rc = zero_area(c, c->scan_ws, l.scan_bytes, ws_ctl(c) + kCtlScanStatus, (uint64_t*)c->ws + kCtlScanResult64, s);
+    if (rc != HVLC_OK) return rc;
+    c->last_op = 2;
     if (!c->scan_blocks_per_cu) c->scan_blocks_per_cu = pick_blocks_per_cu(c, k_exclusive_scan, kThreads, 0, 4);
     const int scan_bpc = c->scan_blocks_per_cu;
     uint64_t grid = (uint64_t)c->cus * (uint64_t)scan_bpc;
@@ -635,7 +653,7 @@ int hvlc_probe_bandwidth(hvlc_ctx* c, const void* d_in, uint64_t n_bytes, void* 
     HVLC_HIP(c, hipEventCreate(&e0));
     HVLC_HIP(c, hipEventCreate(&e1));
     const dim3 grid((unsigned)c->cus * 8u), block(kThreads);      // 32 waves per CU, two 4 KiB steps in flight each
-    uint32_t* sink = (uint32_t*)ws_result(c) + 4;                 // a workspace word nobody reads
+    uint32_t* sink = ws_ctl(c) + 15;                              // a workspace word nobody reads
     std::vector<float> ms((size_t)iters);
     int rc = HVLC_OK;
     for (int i = 0; i < iters && rc == HVLC_OK; ++i) {

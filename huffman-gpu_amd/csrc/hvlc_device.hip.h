@@ -42,7 +42,7 @@
 // Inter-workgroup data are single naturally aligned 4- or 8-byte words carrying their own valid
 // bit, written once with ONE store and read by ONE lane with ONE load of the same width
 // (relaxed agent-scope, sc1) -- the form the CDNA4 guide lists as needing no release/acquire
-// fence -- and zeroed before each launch by k_prepare.
+// fence -- and zero at the start of each launch (by the launch before it: EncodeParams).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -84,43 +84,60 @@ constexpr uint64_t kValMask     = (1ull << 62) - 1;
 //   P    = kValid | global exclusive bit offset of the tile, written by the LAST tile of the tile's
 //          group (the group leader) for all tiles of the group at once;
 //   tail = kValid32 | the last 31 bits of the stream before the tile, written by the tile before it
-//          (record 0: preset by k_prepare); `pad` is never written after k_prepare.
+//          (record 0: by the scout that draws tile 0); `pad` is never written.
 struct alignas(16) TileRec { uint64_t P; uint32_t tail; uint32_t pad; };
 constexpr uint32_t kValid32 = 1u << 31;
 
 enum : uint32_t { kFlagTable = 1u, kFlagCapacity = 2u, kFlagTimeout = 4u, kFlagLayout = 8u };
 
-// Workspace of a context, one allocation: [table 2 KiB][status / result 64 B][granule area ...].  The kernels get ONE
-// base pointer and two byte offsets instead of eight pointers (fewer live scalar registers in k_encode: with eight, the
-// compiler spilled pointers to VGPR lanes and reloaded them in front of the polls).
-constexpr uint32_t kWsLutBytes    = 2048;
-constexpr uint32_t kWsStatusBytes = 64;      // uint32 [0] flags, [1] table layout, uint64 at +8: total bits / scan total
-constexpr uint32_t kWsHeaderBytes = kWsLutBytes + kWsStatusBytes;
-constexpr uint32_t kWsOffBits32   = 64 * 32 * 4;   // granule area: tickets [64 x 128 B] | bits32 | recs | group_desc
+// Workspace of a context, one allocation: [control block 64 B][granule area, half 0][granule area, half 1].
+// ONE kernel launch per hvlc_encode: consecutive calls alternate between the two halves, and every launch, while it works
+// in its own half, zeroes what the call before it used of the OTHER half (each workgroup a slice, at its start) -- so
+// every polled word of a call starts as zero without a reset kernel (and its launch gap) in front.  Which half a launch
+// uses is decided on the device from the context's call counter, so a captured HIP graph can be replayed.
+// Control block, as uint32 words:
+//   [0] [1]  status flags of even / odd calls (atomic RMWs only)      [2..3]  uint64 total bits of the last encode
+//   [4]      calls completed (incremented by the last wave to leave)  [5]     waves that have left the running launch
+//   [6] [7]  bytes the last call in half 0 / 1 used (what the next launch has to zero)
+//   [8]      status flags of the last hvlc_exclusive_scan              [10..11] uint64 its total
+// The kernels get ONE base pointer per area and byte offsets instead of eight pointers (fewer live scalar registers in
+// k_encode: with eight, the compiler spilled pointers to VGPR lanes and reloaded them in front of the polls).
+constexpr uint32_t kWsCtlBytes   = 64;
+constexpr uint32_t kCtlResult64  = 1;              // uint64 index
+constexpr uint32_t kCtlCalls     = 4, kCtlExits = 5, kCtlUsed = 6, kCtlScanStatus = 8;
+constexpr uint32_t kCtlScanResult64 = 5;           // uint64 index
+constexpr uint32_t kWsOffBits32  = 64 * 32 * 4;    // granule area: tickets [64 x 128 B] | bits32 | recs | group_desc
 
 struct EncodeParams {
     const uint4*    in;          // input words, 16-byte aligned
     uint64_t        num_words;
     uint64_t        num_tiles;
     uint64_t        num_segs;
+    const uint32_t* cw;          // the caller's table (device): codewords, lengths (encoder only)
+    const uint32_t* cl;
     uint32_t*       out;         // final stream
     uint64_t        out_cap;     // words
     uint64_t*       offsets;     // per-segment exclusive bit offsets (nullable)
     uint64_t*       total_bits;  // user's device word (nullable)
-    uint8_t*        ws;          // the context's workspace (see above)
+    uint8_t*        ws;          // the context's control block (see above)
+    uint8_t*        gran0;       // encoder: granule area, half 0 (half 1 follows half_bytes behind); scan: the scan's own area
+    uint32_t        half_bytes;
+    uint32_t        used_bytes;  // encoder: bytes of its half this call uses (layout of num_tiles tiles)
     uint32_t        off_recs;    // encoder: byte offset of recs[] in the granule area
     uint32_t        off_groups;  // byte offset of group_desc[] in the granule area (encoder and scan)
+    uint32_t        half;        // encoder: set by the KERNEL (call counter & 1); scan: 0
+    uint32_t        scan;        // 1: k_exclusive_scan's status / result words
     uint64_t        timeout_ticks;   // s_memrealtime ticks (100 MHz)
     uint32_t        stall_tile;      // TEST HOOK: this tile's bit count is never published (~0: none); see hvlc_api.hip
     uint32_t        dbg;             // ablation flags, honoured only in -DHVLC_EXPERIMENT builds (tools/)
     uint64_t*       dbg_tl;          // per-tile timeline [tiles][8] (100 MHz ticks), -DHVLC_EXPERIMENT builds only
     uint64_t*       dbg_ws;          // per-wave time accounting [grid][8 waves][16] (shader clocks), -DHVLC_EXPERIMENT builds only
 
-    __device__ __forceinline__ const uint2* lut() const { return (const uint2*)ws; }              // {codeword (masked), length} x 256, built by k_prepare
-    __device__ __forceinline__ uint32_t* status() const { return (uint32_t*)(ws + kWsLutBytes); }  // flag word (atomic RMWs only), [1] table layout
-    __device__ __forceinline__ uint64_t* result() const { return (uint64_t*)(ws + kWsLutBytes + 8); }
-    __device__ __forceinline__ uint8_t*  gran() const { return ws + kWsHeaderBytes; }
-    // encoder: kTicketClasses counters, kTicketStride words apart (zeroed per call)
+    __device__ __forceinline__ uint32_t* ctl() const { return (uint32_t*)ws; }
+    __device__ __forceinline__ uint32_t* status() const { return (uint32_t*)ws + (scan ? kCtlScanStatus : half); }   // flag word (atomic RMWs only)
+    __device__ __forceinline__ uint64_t* result() const { return (uint64_t*)ws + (scan ? kCtlScanResult64 : kCtlResult64); }
+    __device__ __forceinline__ uint8_t*  gran() const { return gran0 + (half ? half_bytes : 0u); }
+    // encoder: kTicketClasses counters, kTicketStride words apart
     __device__ __forceinline__ uint32_t* tickets() const { return (uint32_t*)gran(); }
     // encoder: word per tile, kValid32 | bits of the tile (group g = words 64g..64g+63)
     __device__ __forceinline__ uint32_t* bits32() const { return (uint32_t*)(gran() + kWsOffBits32); }
@@ -168,7 +185,7 @@ struct WaveStats {
 // small device helpers
 // ---------------------------------------------------------------------------------------------
 // Inter-workgroup words: written once per launch with ONE relaxed agent-scope (sc1, write-through) store,
-// zeroed by k_prepare before every launch, each carrying its own valid bit ("the data is the flag").
+// zero at the start of every launch (EncodeParams), each carrying its own valid bit ("the data is the flag").
 __device__ __forceinline__ uint64_t ld_granule(const uint64_t* p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -299,7 +316,7 @@ __device__ __forceinline__ uint32_t extract_tail(const uint32_t* st, uint32_t e)
 // and serialise 8-way.  hash4() applies the permutation to the four symbols of a word at once.
 __device__ __forceinline__ uint32_t lut_slot(uint32_t s) { return s ^ (s >> 4); }
 __device__ __forceinline__ uint32_t hash4(uint32_t w) { return w ^ ((w >> 4) & 0x0f0f0f0fu); }
-// k_prepare decides per table whether the permutation is needed at all (EncodeParams::status[1]): where the
+// k_encode decides per table whether the permutation is needed at all (its prologue): where the
 // identity layout conflicts no more than the permuted one, the hot loop saves the two instructions per word.
 // Cold paths select at run time:
 __device__ __forceinline__ uint32_t hash4_if(uint32_t w, bool permuted) { return permuted ? hash4(w) : w; }
@@ -447,9 +464,10 @@ struct alignas(16) Smem {
     uint32_t  n_final;                        // scout -> data: the workgroup's tile count once the tickets ran out, else ~0
     uint32_t  n_resolved;                     // scout -> data: tiles whose global offset is known (in order)
     uint32_t  n_bits_pub;                     // data -> scout: tiles whose bit count is published (in order; atomic max)
-    uint32_t  pad0_;
+    uint32_t  n_exited;                       // waves of the workgroup that have left (the last one reports to the context)
     uint32_t  abort_flag;
     uint32_t  pad_[2];
+    uint8_t   len_tmp[256];                   // prologue only: the table's lengths, for the layout decision (not zeroed)
 };
 static_assert(kDataWaves <= 8, "Smem::stored[] and the arrival counter hold up to 8 data waves");
 
@@ -1107,6 +1125,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
                 const uint32_t t = k * (uint32_t)kTicketClasses + ((cls + k) % (uint32_t)kTicketClasses);
                 if (t < ntiles) {       // (a draw in the last, partial block may fall behind the end: draw again)
                     if (lane == 0) {
+                        if (t == 0u) st_word(&p.recs()[0].tail, kValid32);      // nothing precedes tile 0: its predecessor's tail is empty
                         sm.tq[n_tix % kTq] = t;
                         lds_rel(&sm.n_tickets, n_tix + 1u);
                     }
@@ -1275,82 +1294,125 @@ k_encode(EncodeParams p)
     const int lane  = tid & 63;
     const int wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    // ---- which half of the workspace this launch works in: the context's call counter (stable while the launch runs:
+    // only the last wave to leave increments it); zero this workgroup's slice of what the previous call used of the
+    // OTHER half -- the next launch starts there
+    uint32_t* const ctl = p.ctl();
+    {
+        // (calls, exits, used[0], used[1]) in one load: written by the launch before this one, constant while this one runs
+        // (the exits word aside, which nobody reads here)
+        const uint4 c4 = *reinterpret_cast<const uint4*>(ctl + kCtlCalls);
+        p.half = uni(c4.x) & 1u;
+        const uint32_t nvec = uni(p.half ? c4.z : c4.w) / 16u;
+        uint4* const z = reinterpret_cast<uint4*>(p.gran0 + (p.half ? 0u : p.half_bytes));
+        for (uint32_t i = blockIdx.x * (uint32_t)kEncThreads + (uint32_t)tid; i < nvec; i += gridDim.x * (uint32_t)kEncThreads)
+            z[i] = make_uint4(0, 0, 0, 0);
+        if (blockIdx.x == 0 && tid == 0) {
+            __hip_atomic_store(&ctl[kCtlUsed + p.half], p.used_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // every access to a status word is an atomic RMW (set by atomicOr from any XCD, read back the same way): a
+            // plain store was observed to leave a stale flag visible to the next launch
+            (void)atomicExch(&ctl[p.half ^ 1u], 0u);
+        }
+    }
+
     // lut_at() addresses the table absolutely: the workgroup's LDS object must start at LDS address 0
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
-    if ((uint32_t)reinterpret_cast<uintptr_t>((lds_byte*)hvlc_smem_raw) != 0u) {
+    const bool lds_ok = (uint32_t)reinterpret_cast<uintptr_t>((lds_byte*)hvlc_smem_raw) == 0u;
+    if (!lds_ok) {
         if (tid == 0) atomicOr(p.status(), kFlagLayout);
-        return;
-    }
-    const bool permuted = uni(p.status()[1]) != 0u;     // table layout chosen by k_prepare
-    if (tid < 256) sm.lut[permuted ? lut_slot((uint32_t)tid) : (uint32_t)tid] = p.lut()[tid];
-    {   // everything behind the table starts as zero: rings, records, counters
-        uint4* z = reinterpret_cast<uint4*>(&sm.ring[0][0]);
-        const uint32_t nvec = (uint32_t)((sizeof(Smem) - sizeof(sm.lut)) / 16u);
-        for (uint32_t i = (uint32_t)tid; i < nvec; i += (uint32_t)kEncThreads) z[i] = make_uint4(0, 0, 0, 0);
-    }
-    if (blockIdx.x >= (uint32_t)p.num_tiles) return;
-    __syncthreads();                                  // the only workgroup-wide barriers: LDS initialised
-    if (tid == 0) sm.n_final = ~0u;
-    __syncthreads();
+    } else {
+        // ---- the table, straight from the caller's two arrays: validated (workgroup 0 reports), masked, packed into
+        // {codeword, length} pairs.  LDS layout: identity, or slot(s) = s ^ (s >> 4).  A ds_read_b64 serves a group of
+        // 32 lanes in one cycle unless DIFFERENT entries fall into the same pair of banks (slot mod 32).  Expected
+        // conflicting mass with symbol probabilities 2^-len: per bank pair, everything except its most probable entry;
+        // when the identity layout conflicts no more than the permuted one, the hot loop saves two instructions per
+        // word.  Every wave decides for itself, in registers: lane l looks at the four slots l + 64k of either layout
+        // (lut_slot is an involution: slot t of the permuted layout holds symbol lut_slot(t)); lanes l and l ^ 32 share
+        // a bank pair.
+        uint32_t len = 0, code = 0;
+        if (tid < 256) {
+            len  = p.cl[tid];
+            code = p.cw[tid];
+            bool bad = false;
+            if (len > 31u) { bad = true; len = 0u; }
+            else if (len > 0u && (code >> len) != 0u) bad = true;    // cpuencode.cpp:35 precondition
+            if (bad && blockIdx.x == 0) atomicOr(p.status(), kFlagTable);
+            sm.len_tmp[tid] = (uint8_t)len;                          // (one load of the table per workgroup, not per wave)
+        }
+        __syncthreads();
+        uint32_t c0, c1;
+        {
+            uint32_t m0 = 0, t0 = 0, m1 = 0, t1 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t sl = (uint32_t)lane + 64u * (uint32_t)k;
+                const uint32_t l0 = sm.len_tmp[sl], l1 = sm.len_tmp[lut_slot(sl)];
+                const uint32_t w0 = (l0 >= 1u && l0 <= 24u) ? (1u << (24u - l0)) : 0u;
+                const uint32_t w1 = (l1 >= 1u && l1 <= 24u) ? (1u << (24u - l1)) : 0u;
+                m0 += w0; t0 = max(t0, w0); m1 += w1; t1 = max(t1, w1);
+            }
+            m0 += (uint32_t)__shfl_xor((int)m0, 32); t0 = max(t0, (uint32_t)__shfl_xor((int)t0, 32));
+            m1 += (uint32_t)__shfl_xor((int)m1, 32); t1 = max(t1, (uint32_t)__shfl_xor((int)t1, 32));
+            // (both halves of the wave now hold the same 32 sums: the totals count every bank pair twice)
+            c0 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(m0 - t0), 63) / 2u;
+            c1 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(m1 - t1), 63) / 2u;
+        }
+        const bool permuted = !(c0 <= c1 || c0 <= (1u << 24) / 32u);
+        if (tid < 256)
+            sm.lut[permuted ? lut_slot((uint32_t)tid) : (uint32_t)tid] = make_uint2(len ? (code & ((1u << len) - 1u)) : 0u, len);
+        {   // everything behind the table starts as zero: rings, records, counters
+            uint4* z = reinterpret_cast<uint4*>(&sm.ring[0][0]);
+            const uint32_t nvec = (uint32_t)((offsetof(Smem, len_tmp) - sizeof(sm.lut)) / 16u);
+            for (uint32_t i = (uint32_t)tid; i < nvec; i += (uint32_t)kEncThreads) z[i] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();                                  // the only workgroup-wide barriers (three): LDS initialised
+        if (tid == 0) sm.n_final = ~0u;
+        __syncthreads();
 #ifdef HVLC_PRIO_YOUNG
-    if (wave >= 4 && wave < kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_YOUNG);
+        if (wave >= 4 && wave < kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_YOUNG);
 #endif
 #ifdef HVLC_PRIO_SCOUT
-    if (wave == kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_SCOUT);
+        if (wave == kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_SCOUT);
 #endif
-    if (wave == kDataWaves) encode_scout_wave(p, sm, lane);
-    else                    encode_data_wave(p, sm, lane, wave, permuted);
-}
+        if (wave == kDataWaves) encode_scout_wave(p, sm, lane);
+        else                    encode_data_wave(p, sm, lane, wave, permuted);
+    }
 
-// ---------------------------------------------------------------------------------------------
-// k_prepare: block 0 validates the table and packs it into {codeword, length} pairs; all blocks
-// zero the granule arrays (every polled word is re-initialised on every call).  With
-// num_words == 0 it also writes the empty stream (one zero word, cpuencode.cpp:17).
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kThreads) k_prepare(const uint32_t* cw, const uint32_t* cl, uint2* lut,
-                                                      uint32_t* status, uint64_t* result,
-                                                      uint4* granules, uint64_t granule_vecs, uint64_t rec0_vec,
-                                                      uint32_t* out_if_empty, uint64_t out_cap,
-                                                      uint64_t* total_if_empty, int empty)
-{
-    if (blockIdx.x == 0) {
-        __shared__ uint32_t bad;
-        if (threadIdx.x == 0) bad = 0u;
-        __syncthreads();
-        uint32_t len = cl[threadIdx.x], c = cw[threadIdx.x];
-        if (len > 31u) { atomicOr(&bad, kFlagTable); len = 0u; }
-        else if (len > 0u && (c >> len) != 0u) atomicOr(&bad, kFlagTable);   // cpuencode.cpp:35 precondition
-        lut[threadIdx.x] = make_uint2(len ? (c & ((1u << len) - 1u)) : 0u, len);
-        // LDS layout of the table in k_encode: identity, or slot(s) = s ^ (s >> 4).  A ds_read_b64 serves a group of 32 lanes
-        // in one cycle unless DIFFERENT entries fall into the same pair of banks (slot mod 32).  Expected conflicting
-        // mass with symbol probabilities 2^-len: per bank pair, everything except its most probable entry.
-        __shared__ uint32_t mass[2][32], top[2][32];
-        if (threadIdx.x < 64) { (&mass[0][0])[threadIdx.x] = 0u; (&top[0][0])[threadIdx.x] = 0u; }
-        __syncthreads();
-        const uint32_t wgt = (len >= 1u && len <= 24u) ? (1u << (24u - len)) : 0u;
-        if (wgt) {
-            const uint32_t b0 = threadIdx.x & 31u, b1 = lut_slot(threadIdx.x) & 31u;
-            atomicAdd(&mass[0][b0], wgt); atomicMax(&top[0][b0], wgt);
-            atomicAdd(&mass[1][b1], wgt); atomicMax(&top[1][b1], wgt);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t c0 = 0, c1 = 0;
-            for (int b = 0; b < 32; ++b) { c0 += mass[0][b] - top[0][b]; c1 += mass[1][b] - top[1][b]; }
-            status[1] = (c0 <= c1 || c0 <= (1u << 24) / 32u) ? 0u : 1u;      // 1: permuted layout
-            uint32_t f = bad;
-            result[0] = 0ull;
-            if (empty) {
-                if (out_cap >= 1) out_if_empty[0] = 0u; else f |= kFlagCapacity;
-                if (total_if_empty) *total_if_empty = 0ull;
+    // ---- every wave of the grid leaves through here, finished or giving up; the last wave of a workgroup reports for all
+    // eight (one atomic per workgroup on the same word, not eight), the last workgroup closes the call.  (Relaxed atomics:
+    // the counters order nothing inside the launch -- an agent-scope release here is an L2 write-back per wave -- and
+    // the end of the kernel publishes them to the next one.)
+    if (lane == 0) {
+        constexpr uint32_t kWaves = (uint32_t)(kEncThreads / 64);
+        uint32_t report = 1u;                        // (no usable LDS: every wave for itself)
+        if (lds_ok) report = __hip_atomic_fetch_add(&sm.n_exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == kWaves ? kWaves : 0u;
+        if (report) {
+            const uint32_t left = __hip_atomic_fetch_add(&ctl[kCtlExits], report, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + report;
+            if (left == gridDim.x * kWaves) {
+                __hip_atomic_store(&ctl[kCtlExits], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)__hip_atomic_fetch_add(&ctl[kCtlCalls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // every access to the status word is an atomic RMW (set by atomicOr from any XCD, read back the same
-            // way): a plain store here was observed to leave a stale flag visible to the next launch
-            (void)atomicExch(&status[0], f);
         }
     }
-    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < granule_vecs; i += (uint64_t)gridDim.x * kThreads)
-        granules[i] = i == rec0_vec ? make_uint4(0, 0, kValid32, 0) : make_uint4(0, 0, 0, 0);   // nothing precedes tile 0
+}
+
+// The empty input: the stream is one zero word (cpuencode.cpp:17), nothing else runs.
+__global__ void k_encode_empty(uint32_t* out, uint64_t* total)
+{
+    out[0] = 0u;
+    if (total) *total = 0ull;
+}
+
+// The workspace (or a part of it) back to zero: at allocation, and hvlc_exclusive_scan's own area before every scan
+// (its status word only ever sees atomic RMWs, like the encoder's).
+__global__ void __launch_bounds__(kThreads) k_zero(uint4* area, uint64_t vecs, uint32_t* status, uint64_t* result)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < vecs; i += (uint64_t)gridDim.x * kThreads)
+        area[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (status) { (void)atomicExch(&status[0], 0u); (void)atomicExch(&status[1], 0u); }   // (a pair: the encoder's two; the scan's second is unused)
+        if (result) result[0] = 0ull;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1379,14 +1441,6 @@ __global__ void __launch_bounds__(kThreads) k_segment_bits(const uint32_t* in, u
         t = wave_sum_u32(t);
         if (lane == 0) counts[seg] = t;
     }
-}
-
-// Reset for k_exclusive_scan: granules zeroed, status word exchanged (atomic RMW, as k_prepare does), result cleared.
-__global__ void __launch_bounds__(kThreads) k_scan_reset(uint4* granules, uint64_t granule_vecs, uint32_t* status, uint64_t* result)
-{
-    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < granule_vecs; i += (uint64_t)gridDim.x * kThreads)
-        granules[i] = make_uint4(0, 0, 0, 0);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { (void)atomicExch(&status[0], 0u); result[0] = 0ull; }
 }
 
 // Exclusive scan uint32 -> uint64, single launch, wavefront-hierarchical: 16 elements per lane

@@ -20,7 +20,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "libhvlc.so")
 SRC = [os.path.join(HERE, "csrc", "hvlc_api.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", "hvlc_device.hip.h"), os.path.join(ROOT, "include", "hvlc.h")]
+DEPS = SRC + [os.path.join(HERE, "csrc", "hvlc_device.hip.h"), os.path.join(ROOT, "include", "hvlc.h"),
+              os.path.join(HERE, "hazard_pass.py"), os.path.join(HERE, "build_check.py")]
 
 SEGMENT_WORDS = 256
 MAX_CODE_LEN = 31
@@ -50,17 +51,14 @@ def build(force=False, verbose=False):
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     staged = LIB_PATH + ".new"
-    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-o", staged] + SRC
+    # Two steps of our own around hipcc (no plain `hipcc -shared`): hazard_pass.py patches the device assembly so that
+    # no memory instruction takes its address from an SGPR a VALU instruction (a spill reload, v_readfirstlane) wrote a
+    # few wait states earlier -- that sequence read a stale register on MI355X -- and build_check.py verifies the
+    # finished library.
+    hazard_pass, build_check = _load_sibling("hazard_pass"), _load_sibling("build_check")
+    report = hazard_pass.build_library(staged, SRC[0], verbose=verbose)
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=HERE)
-    # Build gate: no memory instruction may take its address from an SGPR that a VALU instruction (a spill reload,
-    # v_readfirstlane) wrote a few wait states earlier -- that sequence read a stale register on MI355X (build_check.py).
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("hvlc_build_check", os.path.join(HERE, "build_check.py"))
-    build_check = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(build_check)
+        print("hazard pass:", {k: v for k, v in report.items() if v} or "nothing to insert")
     found = build_check.check(staged)
     if found:
         os.remove(staged)
@@ -68,6 +66,14 @@ def build(force=False, verbose=False):
                            "\n".join(f"  {k}: `{i}` reads {r} {d} wait states after `{w}`" for k, i, r, d, w in found))
     os.replace(staged, LIB_PATH)
     return LIB_PATH
+
+
+def _load_sibling(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hvlc_" + name, os.path.join(HERE, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 _lib = None

@@ -51,3 +51,64 @@ def test_shipped_library_passes_the_gate():
     if not os.path.exists(os.path.join(bc.LLVM, "llvm-objdump")):
         pytest.skip("no llvm-objdump")
     assert bc.check(lib) == []
+
+
+# ---------------------------------------------------------------------------------------------------------
+# hazard_pass.py: the copies it inserts into the device assembly
+# ---------------------------------------------------------------------------------------------------------
+spec2 = importlib.util.spec_from_file_location("hvlc_hazard_pass", os.path.join(PKG, "hazard_pass.py"))
+hp = importlib.util.module_from_spec(spec2)
+spec2.loader.exec_module(hp)
+
+KERNEL = """\t.text
+\t.type\tk,@function
+k:                                      ; @k
+; %bb.0:
+{body}\ts_endpgm
+.Lfunc_end0:
+\t.size\tk, .Lfunc_end0-k
+"""
+
+
+def _patched(body, window=48):
+    text, rep = hp.patch_asm(KERNEL.format(body=body), window)
+    return [l.strip().split(";")[0].strip() for l in text.splitlines() if l.startswith("\t") and not l.startswith("\t.")], rep["k"]
+
+
+def test_pass_puts_salu_copies_in_front_of_the_faulting_load():
+    body = ("\tv_readlane_b32 s62, v79, 2\n\tv_readlane_b32 s63, v79, 3\n\tv_readlane_b32 s61, v79, 1\n\ts_nop 3\n"
+            "\tglobal_load_dwordx2 v[14:15], v2, s[62:63] sc1\n")
+    ins, n = _patched(body)
+    assert n == 2
+    i = ins.index("global_load_dwordx2 v[14:15], v2, s[62:63] sc1")
+    assert ins[i - 2:i] == ["s_mov_b32 s62, s62", "s_mov_b32 s63, s63"]
+    # the straight-line scanner accepts the result: the SALU copies supersede the VALU writes
+    dis = "0 <k>:\n" + "\n".join("\t" + x for x in ins) + "\n"
+    assert bc.scan(dis, 12) == []
+
+
+def test_pass_follows_branches_and_loops():
+    # the VALU write sits behind the load in program order: only the loop's back edge brings it in front
+    body = ("\ts_mov_b64 s[4:5], s[0:1]\n.LBB0_1:\n\tglobal_load_dword v1, v0, s[4:5]\n\tv_readfirstlane_b32 s4, v1\n"
+            "\ts_cbranch_scc1 .LBB0_1\n")
+    ins, n = _patched(body)
+    assert n == 1 and ins[ins.index("global_load_dword v1, v0, s[4:5]") - 1] == "s_mov_b32 s4, s4"
+    # taken branch over many instructions: the write is old on the fall-through path only
+    pad = "".join("\tv_add_u32_e32 v2, v2, v2\n" for _ in range(60))
+    body = ("\tv_readfirstlane_b32 s6, v1\n\ts_cbranch_scc1 .LBB0_2\n" + pad + ".LBB0_2:\n\tglobal_store_dword v0, v1, s[6:7]\n")
+    ins, n = _patched(body)
+    assert n == 1 and ins[ins.index("global_store_dword v0, v1, s[6:7]") - 1] == "s_mov_b32 s6, s6"
+
+
+def test_pass_leaves_safe_code_alone():
+    pad = "".join("\tv_add_u32_e32 v2, v2, v2\n" for _ in range(60))
+    # written by SALU; written by VALU long ago; VALU-written but rewritten by SALU; SMEM address (interlocked)
+    body = ("\ts_mov_b64 s[4:5], s[0:1]\n\tglobal_load_dword v1, v0, s[4:5]\n"
+            "\tv_readfirstlane_b32 s8, v1\n" + pad + "\tglobal_load_dword v1, v0, s[8:9]\n"
+            "\tv_readfirstlane_b32 s10, v1\n\ts_add_u32 s10, s10, 4\n\tglobal_load_dword v1, v0, s[10:11]\n"
+            "\tv_readfirstlane_b32 s12, v1\n\ts_load_dword s14, s[12:13], 0x0\n")
+    ins, n = _patched(body)
+    assert n == 0
+    # a shorter window trusts more
+    body = "\tv_readfirstlane_b32 s8, v1\n" + "".join("\ts_nop 0\n" for _ in range(20)) + "\tglobal_load_dword v1, v0, s[8:9]\n"
+    assert _patched(body, 48)[1] == 1 and _patched(body, 16)[1] == 0

@@ -676,8 +676,9 @@ def test_two_contexts_on_two_streams_concurrently(golden):
 
 @pytest.mark.gpu
 def test_encode_is_graph_capturable(golden):
-    """hvlc_encode issues two kernel launches and nothing else (no allocation, no synchronisation once the context is
-    sized), so it can be captured into a HIP graph and replayed on new data."""
+    """hvlc_encode issues ONE kernel launch and nothing else (no allocation, no synchronisation once the context is
+    sized), so it can be captured into a HIP graph and replayed on new data -- the launch finds out on the device which
+    half of the workspace is its own (the call counter), so every replay alternates like a direct call."""
     e = hvlc.Encoder(0, 1 << 22)
     x1 = np.tile(golden["period"], 16).view(np.uint32)
     x2 = np.tile(golden["period"][::-1].copy(), 16).view(np.uint32)

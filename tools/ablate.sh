@@ -2,7 +2,7 @@
 # Developer tool: ablation of k_encode phases with the -DHVLC_EXPERIMENT build (wrong outputs by design,
 # timing only).  HVLC_DBG bits: 1 no look-back, 2 no stream stores, 4 no LDS packing, 16 no offsets.
 cd "$(dirname "$0")/.."
-hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -DHVLC_EXPERIMENT $XFLAGS -o huffman-gpu_amd/libhvlc_exp.so huffman-gpu_amd/csrc/hvlc_api.hip || exit 1
+python3 huffman-gpu_amd/hazard_pass.py -o huffman-gpu_amd/libhvlc_exp.so huffman-gpu_amd/csrc/hvlc_api.hip -DHVLC_EXPERIMENT $XFLAGS || exit 1
 export HVLC_LIB=$PWD/huffman-gpu_amd/libhvlc_exp.so
 for dbg in ${DBGS:-0 1 2 4 16 7 23}; do
   echo "== HVLC_DBG=$dbg"

@@ -10,9 +10,9 @@ def one(pat):
     assert g, pat
     return g[0]
 shutil.copy(one("prof/**/*kernel_stats.csv"), os.path.join(dst, f"{R}_kernel_stats.csv"))
-# the trace: k_encode / k_prepare rows only (the generator and histogram launches of the set-up are not the subject)
+# the trace: k_encode rows only (the generator and histogram launches of the set-up are not the subject)
 rows = list(csv.DictReader(open(one("prof/**/*kernel_trace.csv"))))
-keep = [r for r in rows if "k_encode" in r["Kernel_Name"] or "k_prepare" in r["Kernel_Name"]]
+keep = [r for r in rows if "k_encode" in r["Kernel_Name"]]
 with open(os.path.join(dst, f"{R}_kernel_trace.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(keep)
 shutil.copy(one("pmc_fetch/**/*counter_collection.csv"), os.path.join(dst, f"{R}_pmc_fetch_size.csv"))

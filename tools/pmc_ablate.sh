@@ -3,7 +3,7 @@
 # usage (on the GPU box, repo root): bash tools/pmc_ablate.sh "0 1 5 7"
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -DHVLC_EXPERIMENT -DHVLC_NO_CLOCK -o huffman-gpu_amd/libhvlc_exp.so huffman-gpu_amd/csrc/hvlc_api.hip || exit 1
+python3 huffman-gpu_amd/hazard_pass.py -o huffman-gpu_amd/libhvlc_exp.so huffman-gpu_amd/csrc/hvlc_api.hip -DHVLC_EXPERIMENT -DHVLC_NO_CLOCK || exit 1
 export HVLC_LIB=$PWD/huffman-gpu_amd/libhvlc_exp.so
 OUT=gpurun_out/pmcab; mkdir -p $OUT
 for dbg in ${1:-0 1 5 7}; do

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 mkdir -p huffman-gpu_amd/variants
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"; [ "$flags" = "$spec" ] && flags=""
-  hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared $flags -o huffman-gpu_amd/variants/libhvlc_$name.so huffman-gpu_amd/csrc/hvlc_api.hip &
+  python3 huffman-gpu_amd/hazard_pass.py -o huffman-gpu_amd/variants/libhvlc_$name.so huffman-gpu_amd/csrc/hvlc_api.hip $flags &
 done
 wait
 ls -la huffman-gpu_amd/variants/
