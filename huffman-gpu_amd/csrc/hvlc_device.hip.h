@@ -1092,7 +1092,7 @@ struct LeaderDuty {
     uint32_t excl_in = 0;       // per lane: bits of the group's tiles before tile 64g+lane
 };
 
-__device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& sm, int lane)
+__device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& sm, int lane, uint32_t first_ticket)
 {
     // lanes 2q, 2q+1 poll the record of the tile in poll slot q (workgroup-local tile n uses slot n % kMaxPoll):
     // byte offset from p.recs() of the 8 bytes this lane reads (record 0 until a slot is started)
@@ -1106,8 +1106,8 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
     // tickets: draw k of class cls is tile C*k + (cls + k) % C
     const uint32_t cls = blockIdx.x % (uint32_t)kTicketClasses;
     uint32_t n_tix = 0, n_final = ~0u;  // tiles drawn; the total once the tickets ran out
-    bool     tix_inflight = false;
-    uint32_t tix_k = 0;                 // lane 0: the value a ticket draw returned (valid one round later)
+    bool     tix_inflight = true;       // (the first draw was made in the kernel's prologue)
+    uint32_t tix_k = first_ticket;      // lane 0: the value a ticket draw returned (valid one round later)
 
     while (n_done < n_final) {
         bool progress = false;
@@ -1298,6 +1298,9 @@ k_encode(EncodeParams p)
     // only the last wave to leave increments it); zero this workgroup's slice of what the previous call used of the
     // OTHER half -- the next launch starts there
     uint32_t* const ctl = p.ctl();
+    // (the table's loads go out first: they do not depend on the control block, whose load everything else waits for)
+    uint32_t len = 0, code = 0;
+    if (tid < 256) { len = p.cl[tid]; code = p.cw[tid]; }
     {
         // (calls, exits, used[0], used[1]) in one load: written by the launch before this one, constant while this one runs
         // (the exits word aside, which nobody reads here)
@@ -1315,6 +1318,12 @@ k_encode(EncodeParams p)
         }
     }
 
+    // the scout draws the workgroup's first tile right away: the atomic is back by the time LDS is set up
+    uint32_t first_ticket = 0;
+    if (wave == kDataWaves && lane == 0)
+        first_ticket = __hip_atomic_fetch_add(&p.tickets()[(blockIdx.x % (uint32_t)kTicketClasses) * (uint32_t)kTicketStride], 1u,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
     // lut_at() addresses the table absolutely: the workgroup's LDS object must start at LDS address 0
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const bool lds_ok = (uint32_t)reinterpret_cast<uintptr_t>((lds_byte*)hvlc_smem_raw) == 0u;
@@ -1329,10 +1338,7 @@ k_encode(EncodeParams p)
         // word.  Every wave decides for itself, in registers: lane l looks at the four slots l + 64k of either layout
         // (lut_slot is an involution: slot t of the permuted layout holds symbol lut_slot(t)); lanes l and l ^ 32 share
         // a bank pair.
-        uint32_t len = 0, code = 0;
         if (tid < 256) {
-            len  = p.cl[tid];
-            code = p.cw[tid];
             bool bad = false;
             if (len > 31u) { bad = true; len = 0u; }
             else if (len > 0u && (code >> len) != 0u) bad = true;    // cpuencode.cpp:35 precondition
@@ -1374,7 +1380,7 @@ k_encode(EncodeParams p)
 #ifdef HVLC_PRIO_SCOUT
         if (wave == kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_SCOUT);
 #endif
-        if (wave == kDataWaves) encode_scout_wave(p, sm, lane);
+        if (wave == kDataWaves) encode_scout_wave(p, sm, lane, first_ticket);
         else                    encode_data_wave(p, sm, lane, wave, permuted);
     }
 

@@ -8,7 +8,7 @@ src = os.path.join(ROOT, "gpurun_out", "round"); dst = os.path.join(ROOT, "profi
 def one(pat):
     g = glob.glob(os.path.join(src, pat), recursive=True)
     assert g, pat
-    return g[0]
+    return max(g, key=os.path.getmtime)      # (gpurun MERGES into gpurun_out/: an older run's files may still lie there)
 shutil.copy(one("prof/**/*kernel_stats.csv"), os.path.join(dst, f"{R}_kernel_stats.csv"))
 # the trace: k_encode rows only (the generator and histogram launches of the set-up are not the subject)
 rows = list(csv.DictReader(open(one("prof/**/*kernel_trace.csv"))))
@@ -27,10 +27,12 @@ for p in ("sq1", "sq2"):
                         "Counter_Name": r["Counter_Name"], "Counter_Value": r["Counter_Value"]})
 with open(os.path.join(dst, f"{R}_sq_counters.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(out[0].keys())); w.writeheader(); w.writerows(out)
-for n in ("bench_n1", "bench_H2.2-256MiB", "bench_H4.0-4GiB", "bench_H1.0-4GiB", "next_rows", "hist", "mgpu_n1"):
+for n in ("bench_n1", "bench_H2.2-256MiB", "bench_H4.0-4GiB", "bench_H1.0-4GiB", "next_rows", "hist", "mgpu_n1", "host_boundary"):
     p = os.path.join(src, n + ".json")
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{R}_{n}.json"))
+if os.path.exists(os.path.join(src, "slow_path.txt")):
+    shutil.copy(os.path.join(src, "slow_path.txt"), os.path.join(dst, f"{R}_slow_path.txt"))
 b = json.load(open(os.path.join(src, "bench_n1.json")))
 subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), os.path.join(dst, f"{R}_pmc_fetch_size.csv"),
                 os.path.join(dst, f"{R}_pmc_write_size.csv"), str(b["roofline"]["algorithmic_bytes"]), str(rnd)], check=True)
