@@ -54,7 +54,9 @@ typedef enum hvlc_status {
 typedef struct hvlc_ctx hvlc_ctx;   /* workspace: replaces preallocBlockSums/deallocBlockSums (scan.cu:67,98) */
 
 /* Create / destroy a context bound to `device`.  max_words sizes the workspace
- * (20 B per 28 KiB of input); it grows on demand if a later call is larger. */
+ * (2 x 20 B per 28 KiB of input); it grows on demand if a later call is larger
+ * (a re-allocation: synchronises the device, and HIP graphs captured on this
+ * context before it must not be replayed afterwards -- size it up front). */
 int hvlc_create(hvlc_ctx** ctx, int device, uint64_t max_words);
 int hvlc_destroy(hvlc_ctx* ctx);
 
@@ -79,6 +81,8 @@ uint64_t hvlc_num_segments(uint64_t num_words);
  *   d_out_offsets   [hvlc_num_segments] uint64 exclusive bit offsets, or NULL
  *   d_total_bits    uint64 on the device, or NULL (hvlc_finish returns it too)
  *
+ * ONE kernel launch, nothing else (no allocation, no synchronisation, no
+ * memset) once the context is large enough: capturable into a HIP graph.
  * Errors found on the device (table, capacity, timeout) are reported by
  * hvlc_finish.  Not re-entrant per context (one encode in flight per ctx).
  */

@@ -571,6 +571,85 @@ def test_every_part_on_the_slow_path_beyond_one_tile_per_workgroup(kind, mib):
     e.close()
 
 
+def test_call_sequences_on_one_context(golden, monkeypatch):
+    """The two halves of a context's workspace alternate on the DEVICE (call counter) and each launch cleans the other
+    half for the next: every mix of direct calls of different sizes (a later, larger one re-allocates), empty inputs, scans
+    in between, graph replays and a timed-out call must leave the next call a clean half.  Every stream, offset array and
+    total is compared with the oracle."""
+    rng = np.random.default_rng(11)
+    monkeypatch.setenv("HVLC_TIMEOUT_MS", "200")          # read once, by hvlc_create
+    e = hvlc.Encoder(0, 1 << 20)
+    cw, cl = golden["cw"], golden["cl"]
+    d_tab = e.table_to_device(cw, cl)
+    live = np.nonzero(cl)[0]
+
+    def data(nwords):
+        return live[rng.integers(0, live.size, nwords * 4)].astype(np.uint8).view(np.uint32)
+
+    def check(x):
+        out, offs, bits = e.encode(_dev(x), d_tab, max_len=21)
+        ref, rbits = O.encode(x, cw, cl)
+        assert bits == rbits
+        assert np.array_equal(out[: bits // 32 + 1].cpu().numpy().view(np.uint32), ref)
+        _, roffs, _ = O.segment_offsets(x, cl)
+        assert np.array_equal(offs.cpu().numpy().view(np.uint64), roffs)
+
+    def scan(n):
+        c = rng.integers(0, 30000, n, dtype=np.uint64).astype(np.uint32)
+        offs, total = e.exclusive_scan(_dev(c))
+        ref = np.concatenate([[0], np.cumsum(c.astype(np.uint64))])
+        assert np.array_equal(offs.cpu().numpy().view(np.uint64), ref[:-1]) and int(total.item()) == int(ref[-1])
+        bits, rc = e.finish()
+        assert rc == 0 and bits == int(ref[-1])           # hvlc_finish reports on the scan now
+
+    # a captured encode of 300 000 words, replayed between direct calls
+    xg = data(300000)
+    d_in = _dev(xg)
+    gout = torch.empty(hvlc.out_capacity_words(xg.size, 21), dtype=torch.int32, device="cuda")
+    goffs = torch.empty(hvlc.num_segments(xg.size), dtype=torch.int64, device="cuda")
+    gtotal = torch.zeros(1, dtype=torch.int64, device="cuda")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        call = lambda: e.encode_ptr(d_in.data_ptr(), xg.size, d_tab.data_ptr(), d_tab.data_ptr() + 1024,
+                                    gout.data_ptr(), gout.numel(), goffs.data_ptr(), gtotal.data_ptr())
+        call(); st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            call()
+    gref, gbits = O.encode(xg, cw, cl)
+
+    def replay(times):
+        for _ in range(times):
+            gout.fill_(-1)
+            g.replay()
+            torch.cuda.synchronize()
+            assert int(gtotal.item()) == gbits
+            assert np.array_equal(gout[: gbits // 32 + 1].cpu().numpy().view(np.uint32), gref)
+        bits, rc = e.finish()
+        assert rc == 0 and bits == gbits
+
+    check(data(7168 * 40 + 5)); check(data(100)); replay(1); check(data(7168 * 3))
+    scan(100000); check(data(200000)); replay(3); scan(5)
+    out, offs, bits = e.encode(_dev(np.zeros(0, np.uint32)), d_tab, max_len=21)      # the empty input: one zero word
+    assert bits == 0 and int(out[0].item()) == 0
+    check(data(7168 * 64 + 1)); replay(2)
+    # a call that times out (one tile never publishes its bit count) leaves a half dirty and flags set: the next two are clean
+    e.test_hook(hvlc.HOOK_STALL_TILE, 3)
+    x = data(7168 * 20)
+    d_x = _dev(x)
+    tout = torch.empty(hvlc.out_capacity_words(x.size, 21), dtype=torch.int32, device="cuda")
+    e.encode_ptr(d_x.data_ptr(), x.size, d_tab.data_ptr(), d_tab.data_ptr() + 1024, tout.data_ptr(), tout.numel())
+    _, rc = e.finish(check=False)
+    assert rc == hvlc.ERR_TIMEOUT, rc
+    e.test_hook(hvlc.HOOK_STALL_TILE, -1)
+    check(x); check(data(5000))
+    replay(1)
+    # larger than the context was created for: the workspace grows (re-allocated: graphs captured before must not be
+    # replayed afterwards, include/hvlc.h)
+    check(data(3 << 20)); check(data(1234)); check(data(7168 * 9))
+    e.close()
+
+
 # ---------------------------------------------------------------------------------------------------------
 # SURVEY.md section 8(f) "next" rows: seam merge (#1) and decoder (#3)
 # ---------------------------------------------------------------------------------------------------------
