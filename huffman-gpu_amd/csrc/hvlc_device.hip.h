@@ -1,6 +1,6 @@
 // hvlc_device.hip.h -- gfx950 (MI355X, wave64) device code of libhvlc.
 //
-// One fused, single-pass kernel replaces the reference's three GPU stages
+// One fused, single-pass kernel -- ONE launch per hvlc_encode call -- replaces the reference's three GPU stages
 // (vlc_encode_kernel_sm64huff, vlc_kernel_sm64huff.cu:37-160; prescanArray,
 // scan.cu:228; pack2, pack_kernels.cu:19-52): the input is read from HBM once and
 // every word of the final contiguous bit stream is written once, with a plain
@@ -1698,16 +1698,17 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
                     const uint32_t w0 = ring[kk & (kDecRing - 1)][lane], w1 = ring[(kk + 1) & (kDecRing - 1)][lane],
                                    w2 = ring[(kk + 2) & (kDecRing - 1)][lane];
                     uint64_t buf = ((((uint64_t)w0 << 32) | (uint64_t)w1) << sh) | (((uint64_t)w2 << sh) >> 32);
-                    uint32_t word = 0, shortest = 255u;
+                    uint32_t word = 0, len = 0;
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         const uint32_t e = sm.fast[(uint32_t)(buf >> (64 - kDecBits))];
-                        const uint32_t len = e >> 8;
-                        word = (word << 8) | (e & 255u);            // most significant byte first (cpuencode.cpp:28)
+                        len  = e >> 8;
+                        word = __builtin_amdgcn_perm(word, e, 0x06050400u);   // (word << 8) | (e & 255): most significant byte first (cpuencode.cpp:28)
                         buf <<= len; pb += len;
-                        shortest = min(shortest, len);
                     }
-                    const bool redo = shortest == 0u || kk + 2u >= have;     // a long code, or the lane is past its ring
+                    // a long code leaves the buffer where it is, so every lookup behind it reads the same entry: the LAST
+                    // length is 0 exactly when any of the four was
+                    const bool redo = len == 0u || kk + 2u >= have;          // a long code, or the lane is past its ring
                     if (__any(redo)) {
                         const bool far = redo && kk + 6u >= have;            // (even a redo from the ring could run out of it)
                         if (redo && !far) {          // cold: this lane decodes the word again, symbol by symbol, from its ring
