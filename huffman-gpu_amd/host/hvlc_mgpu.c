@@ -191,6 +191,7 @@ int main(int argc, char** argv)
         CHECK_HIP(hipSetDevice(0));
         CHECK_HIP(hipMalloc((void**)&d_merged, merged_words * 4));
         CHECK_HIP(hipMemset(d_merged, 0, merged_words * 4));        /* the seam words are OR-merged: they must start as zero */
+        CHECK_HIP(hipDeviceSynchronize());                          /* ... on device 0, before any peer writes into it */
         for (int g = 1; g < gpus; ++g) {
             int can = 0;
             CHECK_HIP(hipDeviceCanAccessPeer(&can, g, 0));
@@ -202,7 +203,6 @@ int main(int argc, char** argv)
         }
         if (!peer_ok) { fprintf(stderr, "no peer access to device 0: --merge skipped\n"); }
         else {
-            CHECK_HIP(hipDeviceSynchronize());
             const double t0 = now_s();
             uint64_t base = 0;
             for (int g = 0; g < gpus; ++g) {               /* every device writes its own shard: all seams in flight at once */
