@@ -3,9 +3,10 @@
 // Mirrors the call sites of the reference's GPU path in runVLCTest
 // (main_test_cu.cu:130-168): where the reference launches
 // vlc_encode_kernel_sm64huff, then preallocBlockSums/prescanArray/deallocBlockSums,
-// then cudaMemset + pack2 on the default stream, hvlc_encode launches k_prepare
-// (table packing + granule reset) and the fused persistent k_encode on the
-// caller's stream.  Nothing here allocates, frees or synchronises inside the
+// then cudaMemset + pack2 on the default stream, hvlc_encode launches ONE kernel,
+// the fused persistent k_encode, on the caller's stream (the table is packed and
+// the workspace kept clean by that kernel itself: EncodeParams in
+// hvlc_device.hip.h).  Nothing here allocates, frees or synchronises inside the
 // launch path once the workspace is large enough (graph-capture friendly), and
 // nothing falls back to a CPU implementation: without a GPU every compute entry
 // point fails with HVLC_ERR_NO_DEVICE / HVLC_ERR_HIP.
