@@ -112,3 +112,25 @@ def test_pass_leaves_safe_code_alone():
     # a shorter window trusts more
     body = "\tv_readfirstlane_b32 s8, v1\n" + "".join("\ts_nop 0\n" for _ in range(20)) + "\tglobal_load_dword v1, v0, s[8:9]\n"
     assert _patched(body, 48)[1] == 1 and _patched(body, 16)[1] == 0
+
+
+def test_pass_is_complete_and_idempotent_on_the_real_device_code(tmp_path):
+    """The device code of libhvlc as the compiler writes it today: after one pass a second one finds nothing left to do
+    (every VALU-written address register is covered on every path), and the pass only ADDS s_mov copies."""
+    import shutil
+    import subprocess
+    if not shutil.which("hipcc"):
+        pytest.skip("no hipcc")
+    src = os.path.join(PKG, "csrc", "hvlc_api.hip")
+    asm = str(tmp_path / "dev.s")
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-command-line-argument", "-S",
+                    "--cuda-device-only", "-o", asm, src], check=True, cwd=os.path.dirname(src))
+    text = open(asm).read()
+    once, rep1 = hp.patch_asm(text)
+    twice, rep2 = hp.patch_asm(once)
+    assert any("k_encode" in k for k in rep1), "kernels not recognised in the assembly"
+    assert sum(rep2.values()) == 0 and twice == once
+    before = set(text.splitlines())
+    added = [l for l in once.splitlines() if l not in before]
+    assert len(added) == sum(rep1.values())
+    assert all(l.strip().startswith("s_mov_b32") and "hazard pass" in l for l in added)
