@@ -2,6 +2,7 @@
 vectors the reference produced, and -- at BASELINE.json's full sizes -- size-independent
 properties.  Bar: bit-exact (integer/bit work), every word of the stream and every offset."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -483,6 +484,25 @@ def test_config_4GiB_full_compare(enc, golden, name):
     o64[777 * 2048 + 5] += 1
     bad, first = O.compare_stream_mt(x, cw, cl, stream, o64, bits, chunk_segments=2048)
     assert bad == 1 and first == 777 * 2048
+
+
+def test_input_beyond_4GiB_full_compare(golden):
+    """12 GiB of H~2.2 input in ONE call: byte offsets of the input beyond 2^32, 2^33.7 output bits, 440 000 tiles (more
+    than 6 800 groups: the leaders' walk over group granules crosses many 16-granule windows).  The reference cannot
+    run this (32-bit bit offsets, main_test_cu.cu:91-105); word-for-word against the chunked oracle."""
+    n = int(os.environ.get("HVLC_TEST_BIG_GIB", "12")) << 30      # (run by hand with 48: 2^34 input bytes, 2^36.7 bits)
+    e = hvlc.Encoder(0, n // 4)
+    d_in, cw, cl, hist = synth_on_device(e, "H2.2", n, golden["period"])
+    out, offs, bits = e.encode(d_in, e.table_to_device(cw, cl), max_len=int(cl.max()))
+    assert bits == int((hist * cl.astype(np.uint64)).sum()) and bits > 1 << 33
+    x = d_in.cpu().numpy().view(np.uint32)
+    stream = out[: bits // 32 + 1].cpu().numpy().view(np.uint32)
+    o64 = offs.cpu().numpy().view(np.uint64)
+    del out, offs, d_in
+    e.close()
+    torch.cuda.empty_cache()
+    bad, first = O.compare_stream_mt(x, cw, cl, stream, o64, bits, chunk_segments=4096)
+    assert bad == 0, f"{bad} chunks differ, first at segment {first}"
 
 
 def test_two_ranks_on_one_gpu_shared_stitch_code(golden):
