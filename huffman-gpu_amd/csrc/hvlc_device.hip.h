@@ -1429,56 +1429,91 @@ __global__ void __launch_bounds__(kThreads) k_zero(uint4* area, uint64_t vecs, u
 __global__ void __launch_bounds__(kThreads) k_segment_bits(const uint32_t* in, uint64_t num_words,
                                                            const uint32_t* cl, uint32_t* counts, uint64_t num_segs)
 {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lens[256];
     lens[threadIdx.x] = cl[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t nwave = (uint64_t)gridDim.x * 4;
-    for (uint64_t seg = wave0; seg < num_segs; seg += nwave) {
+    const uint64_t full  = num_words / kSegWords;                  // segments that are whole
+    auto bits_of = [&](uint32_t w) { return lens[w >> 24] + lens[(w >> 16) & 255u] + lens[(w >> 8) & 255u] + lens[w & 255u]; };
+    // four whole segments per trip: the four coalesced 16-byte loads go out together (non-temporal: read once)
+    uint64_t seg = wave0;
+    for (; seg + 3 * nwave < full; seg += 4 * nwave) {
+        u32x4 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = __builtin_nontemporal_load((const u32x4*)(in + (seg + r * nwave) * kSegWords) + lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t t = wave_sum_u32(bits_of(v[r].x) + bits_of(v[r].y) + bits_of(v[r].z) + bits_of(v[r].w));
+            if (lane == 0) counts[seg + r * nwave] = t;
+        }
+    }
+    for (; seg < num_segs; seg += nwave) {                          // what is left, and the segment the input ends in
         const uint64_t wbase = seg * kSegWords + (uint64_t)lane * 4u;
         uint32_t t = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (wbase + k < num_words) {
-                const uint32_t w = in[wbase + k];
-                t += lens[w >> 24] + lens[(w >> 16) & 255u] + lens[(w >> 8) & 255u] + lens[w & 255u];
-            }
+            if (wbase + k < num_words) t += bits_of(in[wbase + k]);
         t = wave_sum_u32(t);
         if (lane == 0) counts[seg] = t;
     }
 }
 
-// Exclusive scan uint32 -> uint64, single launch, wavefront-hierarchical: 16 elements per lane
-// serially, DPP scan across the wave, wave totals through LDS, workgroup totals through the same
-// two-level look-back granules as the encoder (replaces scan.cu:67-231 + scanLargeArray_kernel.cu).
+// Exclusive scan uint32 -> uint64, single launch, wavefront-hierarchical.  A workgroup pass covers kScanTile = 4096
+// elements as four rows of 1024; thread t owns elements 4t..4t+3 of every row, so every load is one coalesced 16-byte
+// vector per lane and every store two.  Per row: four elements summed in the lane, DPP scan across the wave (exact
+// 64-bit sums from two 32-bit scans), the (row, wave) totals through LDS; workgroup totals through the same two-level
+// look-back granules as the encoder (replaces scan.cu:67-231 + scanLargeArray_kernel.cu).
 // Only tile_bits / group_desc / status / timeout_ticks / num_tiles of `p` are used.
 __global__ void __launch_bounds__(kThreads) k_exclusive_scan(const uint32_t* in, uint64_t n, uint64_t* out,
                                                              uint64_t* total, EncodeParams p)
 {
-    __shared__ uint64_t wtot[4];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+    static_assert(kScanTile == 16 * kThreads, "four rows of four elements per thread");
+    __shared__ uint64_t wtot[4][4];                      // [row][wave]
     __shared__ uint64_t s_prefix;
     __shared__ uint32_t s_abort;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) s_abort = 0u;
     for (uint64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
-        const uint64_t base = tile * (uint64_t)kScanTile + (uint64_t)tid * 16u;
-        uint32_t v[16];
-        uint64_t sum = 0;
+        const uint64_t tbase = tile * (uint64_t)kScanTile;
+        const bool whole = tbase + kScanTile <= n;
+        u32x4 v[4];
+        uint64_t incl[4], sum[4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { v[k] = base + k < n ? in[base + k] : 0u; sum += v[k]; }
-        // exact 64-bit wave scan from two 32-bit DPP scans: sum < 2^36, so (sum >> 16) < 2^20 and
-        // (sum & 0xffff) < 2^16 stay below 2^32 after adding 64 lanes
-        const uint32_t a = wave_incl_scan((uint32_t)(sum >> 16));
-        const uint32_t b = wave_incl_scan((uint32_t)(sum & 0xffffu));
-        const uint64_t incl = ((uint64_t)a << 16) + b;
+        for (int r = 0; r < 4; ++r) {
+            const uint64_t e = tbase + (uint64_t)r * (4 * kThreads) + (uint64_t)tid * 4u;
+            if (whole) v[r] = __builtin_nontemporal_load((const u32x4*)(in + e));
+            else { v[r].x = e < n ? in[e] : 0u; v[r].y = e + 1 < n ? in[e + 1] : 0u; v[r].z = e + 2 < n ? in[e + 2] : 0u; v[r].w = e + 3 < n ? in[e + 3] : 0u; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sum[r] = (uint64_t)v[r].x + v[r].y + v[r].z + v[r].w;
+            // exact 64-bit wave scan from two 32-bit DPP scans: sum < 2^34, so (sum >> 16) < 2^18 and
+            // (sum & 0xffff) < 2^16 stay below 2^32 after adding 64 lanes
+            const uint32_t a = wave_incl_scan((uint32_t)(sum[r] >> 16));
+            const uint32_t b = wave_incl_scan((uint32_t)(sum[r] & 0xffffu));
+            incl[r] = ((uint64_t)a << 16) + b;
+        }
         __syncthreads();                                  // previous tile's wtot / s_prefix consumed
-        if (lane == 63) wtot[wave] = incl;
+        if (lane == 63) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wtot[r][wave] = incl[r];
+        }
         __syncthreads();
-        const uint64_t w0 = wtot[0], w1 = wtot[1], w2 = wtot[2], w3 = wtot[3];
-        const uint64_t T = w0 + w1 + w2 + w3;
-        const uint64_t wavebase = wave == 0 ? 0ull : wave == 1 ? w0 : wave == 2 ? w0 + w1 : w0 + w1 + w2;
+        uint64_t T = 0, before[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (w == wave) before[r] = T;             // everything in front of (row r, this wave)
+                T += wtot[r][w];
+            }
+        }
         if (tid == 0 && tile != (uint64_t)p.stall_tile) st_granule(&p.tile_bits()[tile], kValid | (T & kValMask));   // (stall_tile: test hook)
         if (wave == 0) {
             uint64_t P = 0;
@@ -1487,10 +1522,22 @@ __global__ void __launch_bounds__(kThreads) k_exclusive_scan(const uint32_t* in,
         }
         __syncthreads();
         if (s_abort) return;
-        uint64_t run = s_prefix + wavebase + (incl - sum);
+        const uint64_t P = s_prefix;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
-        if (tile == p.num_tiles - 1 && tid == kThreads - 1) { p.result()[0] = run; if (total) *total = run; }
+        for (int r = 0; r < 4; ++r) {
+            const uint64_t e = tbase + (uint64_t)r * (4 * kThreads) + (uint64_t)tid * 4u;
+            const uint64_t o0 = P + before[r] + (incl[r] - sum[r]), o1 = o0 + v[r].x, o2 = o1 + v[r].y, o3 = o2 + v[r].z;
+            if (whole) {
+                u64x2* dst = (u64x2*)(out + e);
+                dst[0] = (u64x2){o0, o1}; dst[1] = (u64x2){o2, o3};
+            } else {
+                if (e < n) out[e] = o0;
+                if (e + 1 < n) out[e + 1] = o1;
+                if (e + 2 < n) out[e + 2] = o2;
+                if (e + 3 < n) out[e + 3] = o3;
+            }
+        }
+        if (tile == p.num_tiles - 1 && tid == 0) { p.result()[0] = P + T; if (total) *total = P + T; }
     }
 }
 

@@ -25,6 +25,13 @@ def timed(f, reps=5):
 ms_merge = timed(lambda: e.merge_shard(o, bits, dst, 12345))          # odd bit offset: every word is funnel-shifted
 ms_dec = timed(lambda: e.decode(o, bits, offs, d_tab, n // 4), reps=3)
 stream_bytes = bits / 8
+# the reference pipeline's stage entry points kept as separate calls (include/hvlc.h): per-segment bit counts (A1's outidx)
+# and the stand-alone exclusive scan (A3) of 64 Mi counts
+ms_seg = timed(lambda: e.segment_bits(d_in, d_tab))
+cnt = torch.randint(0, 30000, (64 << 20,), dtype=torch.int32, device="cuda")
+ms_scan = timed(lambda: e.exclusive_scan(cnt))
 print(json.dumps({"workload": f"H2.2 {mib} MiB", "stream_bytes": int(stream_bytes),
                   "merge_ms": round(ms_merge, 3), "merge_GBs_stream_read_plus_write": round(2 * stream_bytes / ms_merge / 1e6, 1),
-                  "decode_ms": round(ms_dec, 3), "decode_GBs_output_bytes": round(n / ms_dec / 1e6, 1)}))
+                  "decode_ms": round(ms_dec, 3), "decode_GBs_output_bytes": round(n / ms_dec / 1e6, 1),
+                  "segment_bits_ms": round(ms_seg, 3), "segment_bits_GBs_input": round(n / ms_seg / 1e6, 1),
+                  "exclusive_scan_64Mi_ms": round(ms_scan, 3), "exclusive_scan_GBs_read_plus_written": round((64 << 20) * 12 / ms_scan / 1e6, 1)}))
