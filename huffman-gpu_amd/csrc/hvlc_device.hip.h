@@ -207,8 +207,6 @@ __device__ __forceinline__ void st_word(uint32_t* p, uint32_t v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
-
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
 {
     (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -471,12 +469,6 @@ struct alignas(16) Smem {
 };
 static_assert(kDataWaves <= 8, "Smem::stored[] and the arrival counter hold up to 8 data waves");
 
-// Granule values a look-back may bring along (k_exclusive_scan passes none).
-struct LbRegs {
-    uint64_t d = 0;     // tile_bits of predecessor tile-1-lane (inside the group)
-    uint64_t v = 0;     // group_desc of group g-1-lane
-};
-
 // Two-level decoupled look-back, executed by ONE wave with all 64 lanes active (k_exclusive_scan).
 // Level 1: lanes 0..r-1 read the sums of the r predecessors inside the tile's group.
 // Level 2: lanes read the granules of up to 64 preceding groups; the nearest inclusive prefix
@@ -484,16 +476,14 @@ struct LbRegs {
 //          group (the "leader") publishes the group's aggregate as soon as level 1 is done and its
 //          inclusive prefix after level 2, so one hop covers 64 tiles / 64 groups.
 // Every granule is ONE naturally aligned 8-byte word read by ONE lane with ONE 8-byte load.
-template <bool WIDE>
-__device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, uint64_t T, int lane, LbRegs L,
-                                         uint64_t& P_out)
+__device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, uint64_t T, int lane, uint64_t& P_out)
 {
     const uint32_t r = (uint32_t)(tile & (kGroupTiles - 1));
     const uint64_t g = tile / kGroupTiles;
     const bool leader = (r == kGroupTiles - 1) || (tile == p.num_tiles - 1);
     Spin spin;
 
-    uint64_t d = L.d;
+    uint64_t d = 0;
     const bool need = (uint32_t)lane < r;
     const uint64_t* src = p.tile_bits() + (need ? tile - 1 - (uint64_t)lane : 0);
     for (;;) {
@@ -502,16 +492,13 @@ __device__ __forceinline__ bool lookback(const EncodeParams& p, uint64_t tile, u
         if (!__any(need && !(d >> 63))) break;
         if (!spin.wait(p)) return false;
     }
-    const uint64_t insum = WIDE ? wave_sum_u64(need ? (d & kValMask) : 0ull)
-                                : (uint64_t)wave_sum_u32(need ? (uint32_t)d : 0u);
+    const uint64_t insum = wave_sum_u64(need ? (d & kValMask) : 0ull);
     if (leader && lane == 0) st_granule(&p.group_desc()[g], kStAgg | ((insum + T) & kValMask));
 
     uint64_t excl = 0;
-    bool first = true;
     for (int64_t gb = (int64_t)g; gb > 0; gb -= 64) {
         const int64_t gi = gb - 1 - lane;
-        uint64_t v = gi < 0 ? kStPre : (first ? L.v : 0ull);   // before the stream: inclusive prefix 0
-        first = false;
+        uint64_t v = gi < 0 ? kStPre : 0ull;                    // before the stream: inclusive prefix 0
         int fp;
         for (;;) {
             const uint64_t pm = __ballot((v >> 62) == 2);
@@ -1517,7 +1504,7 @@ __global__ void __launch_bounds__(kThreads) k_exclusive_scan(const uint32_t* in,
         if (tid == 0 && tile != (uint64_t)p.stall_tile) st_granule(&p.tile_bits()[tile], kValid | (T & kValMask));   // (stall_tile: test hook)
         if (wave == 0) {
             uint64_t P = 0;
-            const bool ok = lookback<true>(p, tile, T, lane, LbRegs(), P);
+            const bool ok = lookback(p, tile, T, lane, P);
             if (lane == 0) { s_prefix = P; if (!ok) s_abort = 1u; }
         }
         __syncthreads();
