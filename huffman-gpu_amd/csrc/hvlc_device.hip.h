@@ -1913,15 +1913,22 @@ __global__ void __launch_bounds__(kThreads) k_histogram(const uint8_t* data, uin
     const u32x4* v = (const u32x4*)data;
     uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * kThreads;
-    for (; i < nvec; i += stride) {      // host sizes the grid so a 32-bit bin cannot overflow
-        const u32x4 x = __builtin_nontemporal_load(v + i);
+    auto count16 = [&](const u32x4 x) {
         const uint32_t w[4] = { x.x, x.y, x.z, x.w };
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             atomicAdd(&mine[w[k] & 255u], 1u); atomicAdd(&mine[(w[k] >> 8) & 255u], 1u);
             atomicAdd(&mine[(w[k] >> 16) & 255u], 1u); atomicAdd(&mine[w[k] >> 24], 1u);
         }
+    };
+    // (host sizes the grid so a 32-bit bin cannot overflow)  Two vectors per trip, both loads in flight before the first
+    // LDS atomic (one load per trip left the memory pipeline idle while the 16 atomics per lane drained: +7..15 %; four
+    // per trip gain nothing more -- the LDS atomics bound it)
+    for (; i + stride < nvec; i += 2 * stride) {
+        const u32x4 x0 = __builtin_nontemporal_load(v + i), x1 = __builtin_nontemporal_load(v + i + stride);
+        count16(x0); count16(x1);
     }
+    for (; i < nvec; i += stride) count16(__builtin_nontemporal_load(v + i));
     if (blockIdx.x == 0)
         for (uint64_t j = nvec * 16 + threadIdx.x; j < n_bytes; j += kThreads) atomicAdd(&mine[data[j]], 1u);
     __syncthreads();
