@@ -641,11 +641,11 @@ int hvlc_probe_bandwidth(hvlc_ctx* c, const void* d_in, uint64_t n_bytes, void* 
                          uint32_t out_words_per_4k, int store_shape, int iters, float* ms_best, float* ms_median)
 {
     if (!c || !d_in || !ms_best || n_bytes < 4096 || ((uintptr_t)d_in & 15u) || iters < 1 || iters > 64 ||
-        store_shape < 0 || store_shape > 2)
+        store_shape < 0 || store_shape > 4)
         return HVLC_ERR_ARG;
     const uint64_t tiles = n_bytes / 4096;
     if (store_shape) {
-        if (!d_out || ((uintptr_t)d_out & 15u) || out_words_per_4k == 0 || (store_shape == 2 && (out_words_per_4k & 3u)) ||
+        if (!d_out || ((uintptr_t)d_out & 15u) || out_words_per_4k == 0 || ((store_shape == 2 || store_shape == 4) && (out_words_per_4k & 3u)) ||
             tiles * (uint64_t)out_words_per_4k * 4u > out_bytes)
             return HVLC_ERR_ARG;
     }
@@ -662,7 +662,9 @@ int hvlc_probe_bandwidth(hvlc_ctx* c, const void* d_in, uint64_t n_bytes, void* 
         if (e == hipSuccess) {
             if (store_shape == 0)      e = launch(k_probe_rw<0>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
             else if (store_shape == 1) e = launch(k_probe_rw<1>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
-            else                       e = launch(k_probe_rw<2>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
+            else if (store_shape == 2) e = launch(k_probe_rw<2>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
+            else if (store_shape == 3) e = launch(k_probe_rw<3>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
+            else                       e = launch(k_probe_rw<4>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
         }
         if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
         if (e == hipSuccess) e = hipEventSynchronize(e1);

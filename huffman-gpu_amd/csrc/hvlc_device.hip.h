@@ -576,9 +576,11 @@ __device__ __forceinline__ void store_words(const EncodeParams& p, const uint32_
     if (HVLC_DBG(p, kDbgNoStore)) return;
     uint32_t* const dst = p.out + ow;                           // scalar base, 32-bit per-lane offsets
     // one word per lane and trip: consecutive lanes read consecutive LDS words (no bank conflicts) and store 256
-    // contiguous bytes per wave-instruction
+    // contiguous bytes per wave-instruction.  Non-temporal: the stream is written once and not read again by this kernel;
+    // at the memory system's limit for this read/write mix that is worth 2-4 % (plain stores: 3.49-3.53 TB/s, 3.25, 4.30
+    // on H2.2 / H4.0 / H1.0 against 3.59-3.61, 3.32, 4.47 in one A/B)
     for (uint32_t k = (uint32_t)lane; k < nown; k += 64u)
-        dst[k] = __builtin_amdgcn_alignbit(sb[k], sb[k + 1], s);
+        __builtin_nontemporal_store(__builtin_amdgcn_alignbit(sb[k], sb[k + 1], s), dst + k);
 }
 
 __device__ __forceinline__ void zero_words(uint32_t* base, uint32_t n_vec4, int lane)
@@ -1516,7 +1518,7 @@ __global__ void __launch_bounds__(kThreads) k_exclusive_scan(const uint32_t* in,
             const uint64_t o0 = P + before[r] + (incl[r] - sum[r]), o1 = o0 + v[r].x, o2 = o1 + v[r].y, o3 = o2 + v[r].z;
             if (whole) {
                 u64x2* dst = (u64x2*)(out + e);
-                dst[0] = (u64x2){o0, o1}; dst[1] = (u64x2){o2, o3};
+                __builtin_nontemporal_store((u64x2){o0, o1}, dst); __builtin_nontemporal_store((u64x2){o2, o3}, dst + 1);
             } else {
                 if (e < n) out[e] = o0;
                 if (e + 1 < n) out[e + 1] = o1;
@@ -1589,7 +1591,7 @@ __global__ void __launch_bounds__(kThreads) k_merge_shard(const uint32_t* __rest
         v.y = s ? __builtin_amdgcn_alignbit(lo.x, lo.y, s) : lo.y;
         v.z = s ? __builtin_amdgcn_alignbit(lo.y, lo.z, s) : lo.z;
         v.w = s ? __builtin_amdgcn_alignbit(lo.z, lo.w, s) : lo.w;
-        *(u32x4*)(dst + w0 + k) = v;
+        __builtin_nontemporal_store(v, (u32x4*)(dst + w0 + k));
     }
     // the words in front of and behind the vector part (the first and the last one of the shard: atomic)
     const uint64_t head = kg < nd ? kg : nd, tail0 = kg + 4 * ng;
@@ -1795,7 +1797,7 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
                 const int j = 16 * t + (lane >> 2), q4 = (lane & 3) * 4;
                 const uint4 v = make_uint4(my[j][q4], my[j][q4 + 1], my[j][q4 + 2], my[j][q4 + 3]);
                 const uint64_t wo = (seg0 + (uint64_t)j) * kSegWords + (uint64_t)chunk * kDecChunk + (uint64_t)q4;
-                if (wo + 3 < num_words) *reinterpret_cast<uint4*>(out + wo) = v;
+                if (wo + 3 < num_words) __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, (u32x4*)(out + wo));
                 else {
                     if (wo     < num_words) out[wo]     = v.x;
                     if (wo + 1 < num_words) out[wo + 1] = v.y;
@@ -1813,6 +1815,7 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
 // and, for the mix, writes `wpt` words per 4 KiB read to a contiguous stream (the stream words of the step before,
 // so that the stores never wait for the loads just issued).
 //   STORE 0: read only   1: one dword per lane per store (the encoder's store shape)   2: dwordx4 per lane
+//         3, 4: the same two with non-temporal stores
 // ---------------------------------------------------------------------------------------------
 template <int STORE>
 __global__ void __launch_bounds__(kThreads) k_probe_rw(const uint4* __restrict__ in, uint64_t tiles4k, uint32_t* __restrict__ out,
@@ -1833,8 +1836,10 @@ __global__ void __launch_bounds__(kThreads) k_probe_rw(const uint4* __restrict__
         // the stores of the PREVIOUS step first, then the next step's loads, then the wait for this step's data
         if (STORE && t != w0) {
             uint32_t* dst = out + (t - nw) * (uint64_t)wpt;
-            if (STORE == 1) { for (uint32_t k = lane; k < wpt; k += 64) dst[k] = prev; }
-            else            { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) *(u32x4*)(dst + k) = (u32x4){prev, prev, prev, prev}; }
+            if (STORE == 1)      { for (uint32_t k = lane; k < wpt; k += 64) dst[k] = prev; }
+            else if (STORE == 2) { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) *(u32x4*)(dst + k) = (u32x4){prev, prev, prev, prev}; }
+            else if (STORE == 3) { for (uint32_t k = lane; k < wpt; k += 64) __builtin_nontemporal_store(prev, dst + k); }
+            else                 { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) __builtin_nontemporal_store((u32x4){prev, prev, prev, prev}, (u32x4*)(dst + k)); }
         }
         u32x4 na = a, nb = b, nc = c, nd = d;
         if (t + nw < tiles4k) {
@@ -1848,8 +1853,10 @@ __global__ void __launch_bounds__(kThreads) k_probe_rw(const uint4* __restrict__
     if (STORE && tiles4k > w0) {                       // the last step's words
         const uint64_t tl = w0 + ((tiles4k - 1 - w0) / nw) * nw;
         uint32_t* dst = out + tl * (uint64_t)wpt;
-        if (STORE == 1) { for (uint32_t k = lane; k < wpt; k += 64) dst[k] = prev; }
-        else            { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) *(u32x4*)(dst + k) = (u32x4){prev, prev, prev, prev}; }
+        if (STORE == 1)      { for (uint32_t k = lane; k < wpt; k += 64) dst[k] = prev; }
+        else if (STORE == 2) { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) *(u32x4*)(dst + k) = (u32x4){prev, prev, prev, prev}; }
+        else if (STORE == 3) { for (uint32_t k = lane; k < wpt; k += 64) __builtin_nontemporal_store(prev, dst + k); }
+        else                 { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) __builtin_nontemporal_store((u32x4){prev, prev, prev, prev}, (u32x4*)(dst + k)); }
     }
     if (acc == 0x12345678u) *sink = acc;
 }

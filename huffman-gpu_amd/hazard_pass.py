@@ -245,7 +245,7 @@ def run(cmd, verbose, **kw):
 
 def build_library(out_path, source, flags=(), window=WINDOW, verbose=False, keep_asm=None):
     """source (.hip) -> out_path (.so) with the pass applied to the device code.  Returns {kernel: copies}."""
-    src = os.path.abspath(source)
+    src, out_path = os.path.abspath(source), os.path.abspath(out_path)
     with tempfile.TemporaryDirectory() as d:
         asm, pasm = os.path.join(d, "dev.s"), os.path.join(d, "dev_patched.s")
         obj, co, fb = os.path.join(d, "dev.o"), os.path.join(d, "dev.co"), os.path.join(d, "dev.hipfb")
@@ -256,7 +256,7 @@ def build_library(out_path, source, flags=(), window=WINDOW, verbose=False, keep
         with open(pasm, "w") as f:
             f.write(text)
         if keep_asm:
-            with open(keep_asm, "w") as f:
+            with open(os.path.abspath(keep_asm), "w") as f:
                 f.write(text)
         run([os.path.join(LLVM, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=" + ARCH, "-c", pasm, "-o", obj], verbose)
         run([os.path.join(LLVM, "ld.lld"), "-shared", obj, "-o", co], verbose)

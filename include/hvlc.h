@@ -150,7 +150,8 @@ int hvlc_profile_collect(hvlc_ctx* ctx, float* ms, int* count);
  * n_bytes from d_in (4 x dwordx4 non-temporal loads per lane per 4 KiB, the encoder's load shape) and, for
  * store_shape != 0, write out_words_per_4k words per 4 KiB read to a contiguous stream in d_out (the encoder's
  * traffic mix: 1024 * bits_per_symbol / 32 words per 4 KiB).  store_shape 0 = read only, 1 = one dword per lane
- * per store instruction (the encoder's store shape), 2 = dwordx4 per lane (out_words_per_4k % 4 == 0).
+ * per store instruction (the encoder's store shape), 2 = dwordx4 per lane (out_words_per_4k % 4 == 0),
+ * 3 / 4 = the same two with non-temporal stores.
  * Synchronous on the default stream; runs `iters` launches and returns the best and the median duration in ms. */
 int hvlc_probe_bandwidth(hvlc_ctx* ctx, const void* d_in, uint64_t n_bytes, void* d_out, uint64_t out_bytes,
                          uint32_t out_words_per_4k, int store_shape, int iters, float* ms_best, float* ms_median);
