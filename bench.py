@@ -249,12 +249,14 @@ def main():
     alg_bytes = n_bytes + (bits + 7) // 8 + 8 * S
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_insts = None, None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch, if profiled
     if os.path.exists(tf):
         try:
             tj = json.load(open(tf))
-            traffic = tj.get(args.workload if not args.size_mib else "", {}).get("hbm_bytes_per_launch")
+            ent = tj.get(args.workload if not args.size_mib else "", {})
+            traffic = ent.get("hbm_bytes_per_launch")
+            valu_insts = ent.get("valu_wave_insts_per_launch")
             traffic_src = "from profile: profiles/traffic.json (rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command, not measured in this run)"
         except Exception:
             traffic = None
@@ -264,6 +266,15 @@ def main():
                 "kernel_ms_median": round(float(np.median(kernel_ms)), 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                 "algorithmic_bytes": int(alg_bytes),
                 "input_only_frac": round(n_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if valu_insts:
+        # SURVEY.md 8(d)'s secondary ceiling, VALU issue: wave64 instructions per launch (SQ_INSTS_VALU of the profiled
+        # command) against what the chip issues -- one integer VALU instruction per 4 clocks per SIMD, measured 0.575 per
+        # ns per SIMD (profiles/r02_ubench.txt), 4 SIMDs per CU
+        cus = enc.launch_info()["compute_units"]
+        peak = 0.575e9 * 4 * cus
+        roofline["valu_issue"] = {"wave_insts_per_launch": int(valu_insts), "peak_wave_insts_per_s": round(peak, 0),
+                                  "frac": round(valu_insts / (k_ms * 1e-3) / peak, 4),
+                                  "source": "from profile: SQ_INSTS_VALU in profiles/traffic.json (not measured in this run)"}
     if probe is not None:
         rd_best, mix_best, wpt = probe
         mix_total = n_bytes * (1.0 + wpt / 1024.0)

@@ -41,4 +41,13 @@ agg = {}
 for r in out:
     agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 tiles = b["config"]["bytes_per_gpu"] / 4096.0
-print({k: round(sum(v) / len(v) / tiles, 1) for k, v in sorted(agg.items())}, "per 4 KiB part")
+per_part = {k: round(sum(v) / len(v) / tiles, 1) for k, v in sorted(agg.items())}
+print(per_part, "per 4 KiB part")
+# the secondary ceiling of SURVEY.md 8(d), VALU issue: instructions per launch from the SQ pass, next to the traffic entry
+tj_path = os.path.join(dst, "traffic.json")
+tj = json.load(open(tj_path))
+tj["H2.2-4GiB"]["valu_wave_insts_per_launch"] = int(round(sum(agg["SQ_INSTS_VALU"]) / len(agg["SQ_INSTS_VALU"])))
+tj["H2.2-4GiB"]["salu_wave_insts_per_launch"] = int(round(sum(agg["SQ_INSTS_SALU"]) / len(agg["SQ_INSTS_SALU"])))
+tj["H2.2-4GiB"]["lds_wave_insts_per_launch"] = int(round(sum(agg["SQ_INSTS_LDS"]) / len(agg["SQ_INSTS_LDS"])))
+tj["H2.2-4GiB"]["sq_source"] = f"profiles/{R}_sq_counters.csv"
+json.dump(tj, open(tj_path, "w"), indent=1)
