@@ -134,3 +134,63 @@ def test_pass_is_complete_and_idempotent_on_the_real_device_code(tmp_path):
     added = [l for l in once.splitlines() if l not in before]
     assert len(added) == sum(rep1.values())
     assert all(l.strip().startswith("s_mov_b32") and "hazard pass" in l for l in added)
+
+
+def test_pass_against_exhaustive_path_search_on_random_programs():
+    """Random control-flow graphs over four SGPRs: after the pass, an exhaustive search over every (block, register ages)
+    state reachable on ANY path -- not the pass's own merged data flow -- finds no memory instruction whose address
+    register a VALU instruction wrote fewer than `window` wait states before with no SALU write in between."""
+    import random
+    W = 6
+    rng = random.Random(5)
+    for trial in range(60):
+        nb = rng.randint(2, 7)
+        body = []
+        for b in range(nb):
+            body.append(f".LBB0_{b}:\n")
+            for _ in range(rng.randint(0, 6)):
+                k, r = rng.random(), rng.randrange(0, 8, 2)
+                if k < 0.30:   body.append(f"\tv_readfirstlane_b32 s{r + rng.randint(0, 1)}, v1\n")
+                elif k < 0.40: body.append(f"\ts_mov_b32 s{r + rng.randint(0, 1)}, s9\n")
+                elif k < 0.60: body.append(f"\ts_nop {rng.randint(0, 3)}\n")
+                elif k < 0.70: body.append("\tv_add_u32_e32 v2, v2, v2\n")
+                else:          body.append(f"\tglobal_load_dword v1, v0, s[{r}:{r + 1}]\n")
+            k = rng.random()
+            if k < 0.45:   body.append(f"\ts_cbranch_scc1 .LBB0_{rng.randrange(nb)}\n")
+            elif k < 0.60: body.append(f"\ts_branch .LBB0_{rng.randrange(nb)}\n")
+        text, _ = hp.patch_asm(KERNEL.format(body="".join(body)), W)
+        # ---- independent check: explicit states, every path
+        lines = [l for l in text.splitlines() if l.strip() and not l.strip().startswith((";", ".t", ".s")) and l.strip() != "k:"]
+        prog, labels = [], {}
+        for l in lines:
+            t = l.split(";")[0].strip()
+            if t.endswith(":"):
+                labels[t[:-1]] = len(prog)
+            elif t and not t.startswith("."):
+                prog.append(t)
+        seen, todo = set(), [(0, (W,) * 8)]
+        while todo:
+            pc, age = todo.pop()
+            while pc < len(prog):
+                if (pc, age) in seen:
+                    break
+                seen.add((pc, age))
+                mnem, _, ops = prog[pc].partition(" ")
+                a = list(age)
+                if mnem.startswith("global_"):
+                    lo = int(ops.split("s[")[1].split(":")[0])
+                    assert a[lo] >= W and a[lo + 1] >= W, (trial, pc, prog[pc], a, "\n".join(prog))
+                ws = 1 + (int(ops) if mnem == "s_nop" else 0)
+                a = [min(W, x + ws) for x in a]
+                if mnem == "v_readfirstlane_b32":
+                    a[int(ops.split(",")[0][1:])] = 0
+                elif mnem == "s_mov_b32":
+                    a[int(ops.split(",")[0][1:])] = W
+                age = tuple(a)
+                if mnem == "s_branch":
+                    pc = labels[ops.strip()]; continue
+                if mnem == "s_cbranch_scc1":
+                    todo.append((labels[ops.strip()], age))
+                if mnem == "s_endpgm":
+                    break
+                pc += 1
