@@ -12,7 +12,7 @@ secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "1")))
 encs = [hvlc.Encoder(0, 1 << 24), hvlc.Encoder(0, 1 << 24)]
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-t0 = time.time(); n = 0; nbytes = 0
+t0 = time.time(); n = 0; nbytes = 0; t_last = t0
 while time.time() - t0 < secs:
     jobs = []
     for i in range(2):
@@ -43,4 +43,6 @@ while time.time() - t0 < secs:
         _, roffs, _ = O.segment_offsets(x, cl)
         assert np.array_equal(offs[: roffs.size].cpu().numpy().view(np.uint64), roffs), ("offsets", x.size)
         n += 1; nbytes += 4 * x.size
+    if time.time() - t_last > 30:                      # (a run that prints nothing for minutes is taken to be hung)
+        t_last = time.time(); print(f"  {n} encodes, {time.time() - t0:.0f} s", flush=True)
 print(f"soak ok: {n} encodes, {nbytes / 1e9:.2f} GB, {time.time() - t0:.0f} s")
