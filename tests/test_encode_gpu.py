@@ -505,6 +505,28 @@ def test_input_beyond_4GiB_full_compare(golden):
     assert bad == 0, f"{bad} chunks differ, first at segment {first}"
 
 
+def test_probe_bandwidth_shapes_and_argument_checks(enc):
+    """hvlc_probe_bandwidth (the measured ceilings of bench.py): every store shape runs, writes exactly the words it is
+    told to and nothing behind them, and bad arguments are refused before anything is launched."""
+    n = 64 << 20
+    d_in = torch.randint(0, 2 ** 31 - 1, (n // 4,), dtype=torch.int32, device="cuda")
+    best, med = enc.probe_bandwidth(d_in)
+    assert 0 < best <= med and n / best / 1e6 > 200          # GB/s: a read-only stream of 64 MiB
+    wpt = 288
+    words = (n // 4096) * wpt
+    for shape in (1, 2, 3, 4):
+        out = torch.full((words + 64,), -1, dtype=torch.int32, device="cuda")
+        best, med = enc.probe_bandwidth(d_in, out, wpt, shape)
+        assert 0 < best <= med
+        assert bool((out[words:] == -1).all()) and not bool((out[:words] == -1).all())
+    with pytest.raises(RuntimeError):
+        enc.probe_bandwidth(d_in, torch.empty(16, dtype=torch.int32, device="cuda"), wpt, 1)      # output too small
+    with pytest.raises(RuntimeError):
+        enc.probe_bandwidth(d_in, torch.empty(words, dtype=torch.int32, device="cuda"), 290, 2)   # dwordx4 stores: multiple of 4
+    with pytest.raises(RuntimeError):
+        enc.probe_bandwidth(d_in, torch.empty(words, dtype=torch.int32, device="cuda"), wpt, 5)   # no such shape
+
+
 def test_two_ranks_on_one_gpu_shared_stitch_code(golden):
     """The code bench.py runs at N > 1, on the one GPU of the test box: two "ranks" = two contexts on two streams.
     Each generates its shard of the job stream (hvlc.shard_first_draw), encodes it from local bit 0, then runs
