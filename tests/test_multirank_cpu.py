@@ -1,4 +1,4 @@
-"""-m "not gpu": the N>1 path on CPU with gloo, world size 2.  The per-shard generator and
+"""-m "not gpu": the N>1 path on CPU with gloo, world sizes 2 and 4.  The per-shard generator and
 encoder here are the ORACLE (tests may use it); what is under test is the product's multi-rank host code, the SAME
 functions bench.py runs at N > 1 -- hvlc.shard_first_draw and hvlc.stitch (one all-gather of one uint64 per rank +
 the rebase) -- against one generation and one encoding of the whole job stream.  tests/test_encode_gpu.py
@@ -7,6 +7,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -73,30 +74,31 @@ def _run(shard_bytes, world=2):
     return res
 
 
-def test_two_rank_job_matches_single_stream(golden):
-    shard_bytes, world = 300 * 1024, 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_job_matches_single_stream(golden, world):
+    shard_bytes = 300 * 1024 if world == 2 else 157 * 1024
     res = _run(shard_bytes, world)
     from util import dist_weights, extract_bits
     cdf = hvlc.cdf32_from_counts(dist_weights("H2.2", golden["period"]))
     whole = O.gen_symbols(world * shard_bytes, 0x5EED0005, cdf)            # ONE generation from draw 0
     cw, cl = np.array(res[0][5], dtype=np.uint32), np.array(res[0][6], dtype=np.uint32)
-    assert res[1][5] == res[0][5] and res[1][6] == res[0][6]               # same table on every rank
+    assert all(r[5] == res[0][5] and r[6] == res[0][6] for r in res)       # same table on every rank
     cw1, cl1 = hvlc.huffman_table(O.histogram(whole))
     assert np.array_equal(cw, cw1) and np.array_equal(cl, cl1)             # ... and it is the whole job's table
     x = whole.view(np.uint32)
     ref_words, ref_bits = O.encode(x, cw, cl)
     _, ref_offs, _ = O.segment_offsets(x, cl)
     totals = res[0][1]
-    assert res[1][1] == totals and totals == [res[0][2], res[1][2]] and sum(totals) == ref_bits
+    assert all(r[1] == totals for r in res) and totals == [r[2] for r in res] and sum(totals) == ref_bits
     # stitched offsets are exactly the single-stream offsets
-    offs = np.array(res[0][3] + res[1][3], dtype=np.uint64)
+    offs = np.array(sum((r[3] for r in res), []), dtype=np.uint64)
     assert np.array_equal(offs, ref_offs)
     # bit-concatenation of the shard streams is the single stream
-    w0 = np.array(res[0][4], dtype=np.uint32)
-    w1 = np.array(res[1][4], dtype=np.uint32)
-    b0, b1 = totals
-    assert np.array_equal(extract_bits(ref_words, 0, b0), extract_bits(w0, 0, b0))
-    assert np.array_equal(extract_bits(ref_words, b0, b1), extract_bits(w1, 0, b1))
+    base = 0
+    for r in res:
+        w = np.array(r[4], dtype=np.uint32)
+        assert np.array_equal(extract_bits(ref_words, base, r[2]), extract_bits(w, 0, r[2]))
+        base += r[2]
 
 
 def test_stitch_is_a_no_op_for_one_rank():
