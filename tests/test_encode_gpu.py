@@ -527,13 +527,14 @@ def test_probe_bandwidth_shapes_and_argument_checks(enc):
         enc.probe_bandwidth(d_in, torch.empty(words, dtype=torch.int32, device="cuda"), wpt, 5)   # no such shape
 
 
-def test_two_ranks_on_one_gpu_shared_stitch_code(golden):
-    """The code bench.py runs at N > 1, on the one GPU of the test box: two "ranks" = two contexts on two streams.
+@pytest.mark.parametrize("world", [2, 5])
+def test_two_ranks_on_one_gpu_shared_stitch_code(golden, world):
+    """The code bench.py runs at N > 1, on the one GPU of the test box: the "ranks" are contexts on streams of their own.
     Each generates its shard of the job stream (hvlc.shard_first_draw), encodes it from local bit 0, then runs
     hvlc.stitch (the all-gather is replaced by a device-side copy of both totals; the rebase is the product's
     hvlc_rebase_offsets_dev), and the shards are merged (hvlc_merge_shard) -- offsets and merged stream must equal the
     oracle's encoding of the whole job stream."""
-    world, shard_bytes = 2, 48 << 20
+    shard_bytes = (48 << 20) if world == 2 else (20 << 20) + 7 * 1024
     period = golden["period"]
     cdf = hvlc.cdf32_from_counts(dist_weights("H2.2", period))
     encs = [hvlc.Encoder(0, shard_bytes // 4) for _ in range(world)]
@@ -545,7 +546,7 @@ def test_two_ranks_on_one_gpu_shared_stitch_code(golden):
         hists.append(encs[r].histogram(d).cpu().numpy().astype(np.uint64))
     whole = O.gen_symbols(world * shard_bytes, 0x5EED0005, cdf)                 # ONE generation from draw 0
     assert np.array_equal(np.concatenate([s.cpu().numpy() for s in shards]), whole)
-    cw, cl = hvlc.build_table(hists[0] + hists[1])                             # table of the job histogram
+    cw, cl = hvlc.build_table(sum(hists[1:], hists[0]))                        # table of the job histogram
     S = hvlc.num_segments(shard_bytes // 4)
     outs, offs, totals = [], [], []
     gathered = torch.zeros(world, dtype=torch.int64, device="cuda")
