@@ -9,13 +9,16 @@ Scans the gfx950 code object for the sequence that faulted in round 2:
 
 On MI355X the load was seen (rarely: once per ~10^8 executions, in the scouts' polling loop) to use the OLD value of
 s63: "Memory access fault ... on address 0xffff1ca03000" = {new low half, stale high half = -1}.  The same code with
-the s_nop lengthened never faulted (profiles/README.md, "the readlane hazard").  hazard_pass.py therefore puts a SALU
+the s_nop lengthened never faulted (profiles/r02_hazard_ab.txt).  The root cause (tools/hazard_repro.hip): an s_wakeup
+from another wave of the workgroup ends an s_nop in progress.  hazard_pass.py therefore splits the multi-state s_nop of
+kernels that use s_wakeup and puts a SALU
 copy of the register onto itself (interlocked in hardware) in front of every such memory instruction, on any path; this
 script is the independent check of the binary that ships:
 
     python huffman-gpu_amd/build_check.py [libhvlc.so] [--min-wait-states 12]
 
-exits 1 and lists every VMEM instruction that reads an SGPR some VALU instruction wrote fewer than --min-wait-states wait
+exits 1 and lists every multi-state `s_nop` left in a kernel that uses s_wakeup (the root cause: a wake-up from another
+wave ends an s_nop in progress) and every VMEM instruction that reads an SGPR some VALU instruction wrote fewer than --min-wait-states wait
 states earlier with no SALU write of it in between (straight-line distance in the disassembly; a label in between does
 not reset it, which is conservative for fall-through; paths through taken branches are hazard_pass.py's data-flow
 analysis).  SMEM addresses are interlocked like SALU reads and not listed.  hvlc.build() refuses a library that fails;
@@ -64,6 +67,25 @@ def extract_code_object(lib, workdir):
     return cos[0]
 
 
+def multi_state_nops(disassembly):
+    """[(kernel, instruction)]: every `s_nop N`, N > 0, in a kernel that also executes s_wakeup (an s_wakeup from another
+    wave of the workgroup ends an s_nop in progress: hazard_pass.py splits them)."""
+    kernels, cur = {}, None
+    for line in disassembly.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), [False, []])
+            continue
+        if cur is None or not line.startswith("\t"):
+            continue
+        ins = line.split("//")[0].strip()
+        if ins.startswith("s_wakeup"):
+            cur[0] = True
+        elif ins.startswith("s_nop") and int(ins.split()[1], 0) > 0:
+            cur[1].append(ins)
+    return [(k, i) for k, (wakes, nops) in kernels.items() if wakes for i in nops]
+
+
 def scan(disassembly, min_ws):
     findings = []
     kernel = "?"
@@ -109,7 +131,7 @@ def check(lib, min_ws=12):
     with tempfile.TemporaryDirectory() as d:
         co = extract_code_object(lib, d)
         dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
-    return scan(dis, min_ws)
+    return scan(dis, min_ws) + [(k, i, "-", 0, "a kernel that uses s_wakeup must not rely on a multi-state s_nop") for k, i in multi_state_nops(dis)]
 
 
 def main():
