@@ -62,8 +62,9 @@ def build(force=False, verbose=False):
     found = build_check.check(staged)
     if found:
         os.remove(staged)
-        raise RuntimeError("libhvlc.so refused, VALU-written SGPR feeds a memory address:\n" +
-                           "\n".join(f"  {k}: `{i}` reads {r} {d} wait states after `{w}`" for k, i, r, d, w in found))
+        raise RuntimeError("libhvlc.so refused by build_check.py:\n" +
+                           "\n".join((f"  {k}: `{i}`: {w}" if r == "-" else f"  {k}: `{i}` reads {r} {d} wait states after `{w}`")
+                                     for k, i, r, d, w in found))
     os.replace(staged, LIB_PATH)
     return LIB_PATH
 
