@@ -11,21 +11,23 @@
 //   segment  256 input words = 1024 symbols  = ONE WAVE-ROW (64 lanes x 16 bytes);
 //            the reference's block (main_test_cu.cu:43); unit of out_offsets
 //   part     4 segments = 4 KiB              = what ONE data wave encodes per tile
-//   tile     28 segments = 28 KiB            = the 7 parts of a workgroup's 7 data waves;
+//   tile     40 segments = 40 KiB            = the 10 parts of a workgroup's 10 data waves;
 //            data wave w owns the tile's segments 4w..4w+3; unit of the look-back
-//   group    64 tiles = 1.75 MiB             = unit of the second scan level
+//   group    64 tiles = 2.5 MiB              = unit of the second scan level
 //
-// Workgroup = 7 DATA waves + 1 SCOUT wave (two waves per SIMD), three workgroups per CU.
-// The data waves never wait for each other (no barrier after the LDS set-up).  A data wave, per
-// tile: (1) coalesced non-temporal dwordx4 loads (next tile prefetched); (2) per-lane LDS table
-// lookups (one SDWA op per address) and 64-bit concatenation of 16 symbols; (3) wave64 DPP
+// Workgroup = 10 DATA waves + 1 SCOUT wave + 1 STORE wave (three waves per SIMD), two workgroups per CU.
+// The data waves never wait for each other (no barrier after the LDS set-up) and never touch the output.
+// A data wave, per tile: (1) coalesced non-temporal dwordx4 loads (next tile prefetched); (2) per-lane LDS
+// table lookups (one SDWA op per address) and 64-bit concatenation of 16 symbols; (3) wave64 DPP
 // prefix scan of the bit lengths per segment; (4) it ARRIVES at the tile (one LDS atomic add of
 // its bit count): the last wave to arrive PUBLISHES the tile's bit count (one self-validating
 // word, relaxed agent-scope store); (5) "pabio": each lane ORs its <=64 bits into the wave's
 // OWN LDS staging ring with 3 ds_or_b32 at PART-LOCAL bit positions (so packing waits for
-// nothing); (7) several tiles later, once the scout has seen the tile's global bit offset, the
-// part's ring words are funnel-shifted (v_alignbit_b32) by offset%32 and stored with coalesced
-// dword stores; segment offsets are written as uint64.
+// nothing).  Store wave: (7) several tiles later, once the scout has seen the tile's global bit offset,
+// it walks the tile's stretch of the stream in 256-byte blocks aligned by ADDRESS, funnel-shifts the ring
+// words of the part a word belongs to (v_alignbit_b32) and stores one block per instruction -- the block in
+// which one part ends and the next begins is ONE instruction fed from two rings -- so that a tile leaves as one
+// burst of whole lines; it writes the segment offsets (uint64), zeroes the ring words and hands them back.
 // Scout wave: draws the workgroup's tiles from ticket counters, and (6) polls ONE 16-byte record
 // per tile in flight (global offset + the predecessor's <=31 carry bits).  The offsets come
 // from a two-level scan: the scout of the LAST tile of each 64-tile group reads the group's 64
@@ -52,18 +54,19 @@ namespace hvlc {
 
 constexpr int      kThreads     = 256;                     // block size of the small kernels
 #ifndef HVLC_DATA_WAVES
-#define HVLC_DATA_WAVES 7
+#define HVLC_DATA_WAVES 10
 #endif
-constexpr int      kDataWaves   = HVLC_DATA_WAVES;         // data waves per encoder workgroup (+1 scout wave)
+constexpr int      kDataWaves   = HVLC_DATA_WAVES;         // data waves per encoder workgroup (+1 scout wave, +1 store wave)
 constexpr int      kDataThreads = 64 * kDataWaves;
-constexpr int      kEncThreads  = kDataThreads + 64;       // k_encode: 7+1 waves = two waves per SIMD whatever the placement
+constexpr int      kEncThreads  = kDataThreads + 128;      // k_encode: 10+1+1 waves = three waves per SIMD whatever the placement
 #ifndef HVLC_ROWS
 #define HVLC_ROWS 4
 #endif
 constexpr int      kRows        = HVLC_ROWS;               // 16-byte rows per lane per tile
-constexpr int      kTileWords   = kDataThreads * kRows * 4;   // 7168 words = 28 KiB
+constexpr int      kTileWords   = kDataThreads * kRows * 4;   // 10240 words = 40 KiB
 constexpr int      kSegWords    = 256;
-constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 28: wave w owns segments 4w..4w+3
+constexpr int      kSegsPerTile = kTileWords / kSegWords;  // 40: wave w owns segments 4w..4w+3
+static_assert(kSegsPerTile <= 64, "the store wave writes a tile's segment offsets with one lane per segment");
 #ifndef HVLC_GROUP_TILES
 #define HVLC_GROUP_TILES 64
 #endif
@@ -413,15 +416,18 @@ __device__ __forceinline__ void put_row_pairs_mem(uint32_t* st, uint32_t q, cons
 // ---------------------------------------------------------------------------------------------
 // LDS of an encoder workgroup.
 //
-// The DATA WAVES NEVER WAIT FOR EACH OTHER: wave w owns segments 4w..4w+3 of every tile of its workgroup (its
-// PART of the tile), packs them into its OWN staging ring at part-local bit positions and stores them, several
-// tiles later, once the scout has seen the tile's global bit offset.  What the waves of a workgroup tell each
-// other goes through small LDS records, written once per (tile, wave) and never waited for on the fast path:
-//   WaveRec  per (slot, wave)   bits of the part, its last 31 stream bits, where it sits in the ring
+// The DATA WAVES NEVER WAIT FOR EACH OTHER and never touch the output: wave w owns segments 4w..4w+3 of every tile
+// of its workgroup (its PART of the tile), packs them into its OWN staging ring at part-local bit positions and
+// goes on to the next tile.  The workgroup's STORE WAVE takes a tile once the scout has seen its global bit offset:
+// it stores the tile's stretch of the stream out of the ten rings, zeroes the ring words and hands them back
+// (Smem::n_freed).  What the waves of a workgroup tell each other goes through small LDS records, written once per
+// (tile, wave) and never waited for on the data waves' fast path:
+//   WaveRec  per (slot, wave)   bits of the part, where it sits in the ring; its last 31 stream bits where a slow
+//                               part needs them
 //   TileSlot per slot           arrival counter + bit sum (the LAST wave to arrive publishes the tile's bit count
 //                               and every part's base), and the scout's result (global offset, predecessor tail)
-// A workgroup's n-th tile uses slot n % kSlots; a slot is reused only after every wave has stored its part of
-// the slot's previous tile (Smem::stored[]), so the fastest wave runs at most kSlots-1 tiles ahead of the slowest.
+// A workgroup's n-th tile uses slot n % kSlots; a slot is reused only after the store wave has freed the slot's
+// previous tile, so the fastest data wave runs at most kSlots-1 tiles ahead of the store wave.
 // ---------------------------------------------------------------------------------------------
 constexpr int      kSlots   = 8;
 constexpr int      kTq      = 16;                          // queue of drawn tile numbers: workgroup-local tile n at [n % kTq]
@@ -429,18 +435,19 @@ constexpr int      kTq      = 16;                          // queue of drawn til
 #define HVLC_TICKETS_AHEAD 2
 #endif
 constexpr int      kTixAhead = HVLC_TICKETS_AHEAD;         // tiles the scout draws ahead of the workgroup's slowest data wave
-static_assert(kTq >= kSlots + kTixAhead + 2, "a tile number must stay in the queue until every wave has stored the tile");
+static_assert(kTq >= kSlots + kTixAhead + 2, "a tile number must stay in the queue until the store wave has stored the tile");
 #ifndef HVLC_WAVE_RING_WORDS
 #define HVLC_WAVE_RING_WORDS 1752
 #endif
-constexpr uint32_t kWaveRing = HVLC_WAVE_RING_WORDS;       // staging ring of ONE data wave: 7 x 6.8 KiB per workgroup, three workgroups per CU
+constexpr uint32_t kWaveRing = HVLC_WAVE_RING_WORDS;       // staging ring of ONE data wave: 10 x 6.8 KiB per workgroup, two workgroups per CU
 constexpr uint32_t kNoRoom   = 0xffffffffu;
 constexpr uint32_t kRowWordsMax = 1024u * 31u / 32u + 8u;  // slow path: one segment at 31 bits per symbol + carry word + read-ahead
 static_assert(kWaveRing % 4 == 0 && kWaveRing >= kRowWordsMax, "the slow path stages one segment in the (empty) ring");
+constexpr uint32_t kBlockWords = 64;                       // the store wave's unit: one dword per lane = 256 bytes per instruction
 
 struct alignas(16) WaveRec {
     uint32_t bits;            // T_w: bits of this wave's part of the tile
-    uint32_t tail;            // kValid32 | the last 31 stream bits up to the end of the part; 0 until known
+    uint32_t tail;            // kValid32 | the last 31 stream bits up to the end of the part; 0 until known (slow paths only)
     uint32_t start, need;     // ring words [start, start + need) hold the packed part; start = its carry word
     uint32_t base;            // bits of the tile in front of the part (written by the tile's last arriver)
     uint32_t rb1, rb2, rb3;   // bit offsets of segments 1..3 inside the part (segment 0 starts at 0)
@@ -448,26 +455,29 @@ struct alignas(16) WaveRec {
 struct alignas(16) TileSlot {
     uint64_t prefix;          // scout: global exclusive bit offset of the tile
     uint32_t pred_tail;       // scout: the last 31 bits of the stream before the tile
-    uint32_t arrive;          // data waves: (arrivals << 24) | bits so far (a tile holds < 2^20 bits)
+    uint32_t arrive;          // data waves: (arrivals << 24) | bits so far (a tile holds < 2^21 bits)
 };
+static_assert((uint64_t)kTileWords * 4u * 31u < (1ull << 24), "the arrival counter's bit sum");
 
 struct alignas(16) Smem {
     uint2     lut[256];                       // 2 KiB: {codeword, length}; MUST be first (lut_at() addresses it absolutely)
     uint32_t  ring[kDataWaves][kWaveRing];    // per-wave staging rings
     WaveRec   wrec[kSlots][kDataWaves];
     TileSlot  ts[kSlots];
-    uint32_t  stored[8];                      // data wave w: parts stored so far (slot reuse gate)
-    uint32_t  tq[kTq];                        // scout -> data: tile number of the workgroup's n-th tile
+    uint32_t  packed[16];                     // data wave w: parts packed (or, slow parts, stored) so far -> store wave
+    uint32_t  tq[kTq];                        // scout -> data, store: tile number of the workgroup's n-th tile
     uint32_t  n_tickets;                      // scout -> data: tiles drawn so far (release)
-    uint32_t  n_final;                        // scout -> data: the workgroup's tile count once the tickets ran out, else ~0
-    uint32_t  n_resolved;                     // scout -> data: tiles whose global offset is known (in order)
+    uint32_t  n_final;                        // scout -> data, store: the workgroup's tile count once the tickets ran out, else ~0
+    uint32_t  n_resolved;                     // scout -> store: tiles whose global offset is known (in order)
     uint32_t  n_bits_pub;                     // data -> scout: tiles whose bit count is published (in order; atomic max)
+    uint32_t  n_freed;                        // store -> data: tiles stored, their ring words zeroed (in order)
     uint32_t  n_exited;                       // waves of the workgroup that have left (the last one reports to the context)
     uint32_t  abort_flag;
-    uint32_t  pad_[2];
+    uint32_t  pad_[1];
     uint8_t   len_tmp[256];                   // prologue only: the table's lengths, for the layout decision (not zeroed)
 };
-static_assert(kDataWaves <= 8, "Smem::stored[] and the arrival counter hold up to 8 data waves");
+static_assert(kDataWaves <= 16, "Smem::packed[] and the arrival counter hold up to 16 data waves");
+static_assert(2 * sizeof(Smem) <= 160 * 1024, "two workgroups per CU");
 
 // Two-level decoupled look-back, executed by ONE wave with all 64 lanes active (k_exclusive_scan).
 // Level 1: lanes 0..r-1 read the sums of the r predecessors inside the tile's group.
@@ -624,25 +634,6 @@ struct WaveWait {
     }
 };
 
-// Per-wave control state of a data wave (all wave-uniform).
-struct WaveCtl {
-    uint32_t m_loaded = 0, m_packed = 0, m_stored = 0;   // workgroup-local tile indices: input loaded / part packed / part stored
-    uint32_t head = 0;                                    // staging ring: where the next part's words start
-};
-
-// Where `need` words fit in the wave's staging ring: kNoRoom = nowhere for now.  Allocations are contiguous (a part
-// that does not fit before the end of the ring starts over at word 0) and are released in order.
-__device__ __forceinline__ uint32_t ring_place(const WaveCtl& c, const Smem& sm, int wave, uint32_t need)
-{
-    if (c.m_packed == c.m_stored) return 0u;                                   // empty (need <= kWaveRing is the caller's business)
-    const uint32_t tail = uni(sm.wrec[c.m_stored % kSlots][wave].start);       // oldest part still in the ring
-    if (c.head > tail) {
-        if (c.head + need <= kWaveRing) return c.head;
-        return need <= tail ? 0u : kNoRoom;
-    }
-    return (c.head < tail && need <= tail - c.head) ? c.head : kNoRoom;         // head == tail with parts in flight: full
-}
-
 // The tail of a part once the tail of what precedes it is known: its own last 31 bits, or, if it is shorter,
 // the predecessor's bits shifted up with its own appended.
 __device__ __forceinline__ uint32_t chain_tail(uint32_t pred_tail, uint32_t own, uint32_t T)
@@ -685,44 +676,6 @@ __device__ __forceinline__ bool pred_tail_of(const EncodeParams& p, Smem& sm, ui
         if (v & kValid32) { pt = v & 0x7fffffffu; return true; }
         if (!w.step(p, sm, lane)) return false;
     }
-}
-
-// Store the packed part j (workgroup-local tile index) of this wave: everything that needs the tile's global
-// offset -- the finished words, the segment offsets, the total on the last part of the stream, a late tail.
-__device__ __forceinline__ bool store_part(const EncodeParams& p, Smem& sm, uint32_t* ring, uint32_t j, int wave, int lane)
-{
-    const uint32_t slot = j % kSlots;
-    const WaveRec& r = sm.wrec[slot][wave];
-    const uint4 ra = *reinterpret_cast<const uint4*>(&r.bits);      // bits, tail, start, need
-    const uint4 rb = *reinterpret_cast<const uint4*>(&r.base);      // base, rb1, rb2, rb3
-    const uint32_t T = uni(ra.x), own_tail = uni(ra.y), start = uni(ra.z), need = uni(ra.w);
-    const uint32_t tile = uni(sm.tq[j % kTq]);
-    const uint64_t G = uni64(sm.ts[slot].prefix) + (uint64_t)uni(rb.x);   // global bit offset of the part
-    uint32_t pt;
-    if (!pred_tail_of(p, sm, slot, wave, lane, pt)) return false;
-    uint32_t* const sb = ring + start;
-    if (lane == 0) sb[0] = pt;                                      // carry word (same-wave LDS operations complete in order)
-    TL(p, tile, 5, lane == 0 && wave == 0);
-    if (p.offsets && lane < kRows && !HVLC_DBG(p, kDbgNoOffsets)) {
-        const uint64_t seg = (uint64_t)tile * kSegsPerTile + (uint64_t)(wave * kRows + lane);
-        const uint32_t rel = lane == 0 ? 0u : lane == 1 ? rb.y : lane == 2 ? rb.z : rb.w;
-        if (seg < p.num_segs) p.offsets[seg] = G + rel;
-    }
-    const bool last = (tile == (uint32_t)(p.num_tiles - 1)) && wave == kDataWaves - 1;
-    if (last && lane == 0) {
-        p.result()[0] = G + T;
-        if (p.total_bits) *p.total_bits = G + T;
-    }
-    // the last part of the stream also stores the open word, zero padded, and the zero word cpu_vlc_encode leaves
-    // behind when the stream ends on a word boundary (cpuencode.cpp:39)
-    const uint32_t s = (uint32_t)G & 31u;
-    uint32_t nown = (s + T) >> 5;
-    if (last) nown = ((s + T + 31u) >> 5) + ((((s + T) & 31u) == 0u) ? 1u : 0u);
-    store_words(p, sb, s, G >> 5, nown, lane);
-    if (!(own_tail & kValid32))                                    // a part shorter than 31 bits: its tail needed the predecessor's
-        publish_tail<true>(p, sm, slot, wave, tile, chain_tail(pt, extract_tail(sb + 1, T), T), lane);
-    zero_words(sb, need / 4u, lane);
-    return true;
 }
 
 // The tail (last 31 stream bits) of a FULL part that will take the slow path, computed at pack time from its last
@@ -774,6 +727,7 @@ __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint3
     const uint32_t slot = j % kSlots;
     uint64_t G = uni64(sm.ts[slot].prefix) + (uint64_t)uni(sm.wrec[slot][wave].base);
     uint32_t carry = 0;
+    zero_words(ring, (kRowWordsMax + 3u) / 4u, lane);          // (packed parts leave their words behind: the ring is empty, not clean)
     const bool last_part = (tile == (uint32_t)(p.num_tiles - 1)) && wave == kDataWaves - 1;
     const uint32_t* in32 = (const uint32_t*)p.in;
 #pragma unroll 1
@@ -815,18 +769,39 @@ __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint3
     return true;
 }
 
+// Ring words a packed part of T bits takes: carry word + data + the two words behind the data that pack / store touch.
+__device__ __forceinline__ uint32_t ring_need(uint32_t T) { return (((T + 31u) >> 5) + 3u + 3u) & ~3u; }
+// Is (tile, wave)'s part of T bits packed into its wave's ring (the fast path), or does it take the slow path?
+// Wave-uniform; the data wave and the store wave answer it the same way (T is in the part's record once it arrived).
+__device__ __forceinline__ bool part_is_fast(const EncodeParams& p, uint32_t tile, int wave, uint32_t T)
+{
+    return (tile != (uint32_t)(p.num_tiles - 1) || part_is_full(p, tile, wave)) && ring_need(T) <= kWaveRing;
+}
+
+// Where `need` words fit in a data wave's staging ring: kNoRoom = nowhere for now.  Allocations are contiguous (a part
+// that does not fit before the end of the ring starts over at word 0) and are released in order, a tile at a time, by
+// the store wave: `freed` tiles of the workgroup are stored, this wave has `packed` parts in (or through) its ring.
+__device__ __forceinline__ uint32_t ring_place(const Smem& sm, int wave, uint32_t head, uint32_t packed, uint32_t freed, uint32_t need)
+{
+    if (freed >= packed) return 0u;                                            // empty: start over at word 0 (need <= kWaveRing is the caller's business)
+    const uint32_t tail = uni(sm.wrec[freed % kSlots][wave].start);            // oldest part still in the ring
+    if (head > tail) {
+        if (head + need <= kWaveRing) return head;
+        return need <= tail ? 0u : kNoRoom;
+    }
+    return (head < tail && need <= tail - head) ? head : kNoRoom;              // head == tail with parts in flight: full
+}
+
 // ------------------------------------------------------------------------------------------------
 // A DATA wave of the pipelined encoder.  One loop iteration = one tile of the workgroup, this wave's part:
 //   1  wait for the part's input (loaded during the previous iteration), look up / concatenate its 4 x 16 symbols
 //      per lane (registers only), DPP-scan the lane-row bit counts
-//   2  store the OLDEST packed part if the scout has resolved its tile (funnel shift out of the ring, coalesced
-//      dword stores) -- in front of the prefetch: vector-memory operations retire in order, so a store issued
-//      behind the prefetch loads would delay nothing, but a load wait behind a store waits for the store's
-//      acknowledgement; here the stores have a whole iteration to complete
-//   3  issue the loads of the next tile's part into the registers the lookups just vacated
-//   4  take the part's words in the ring, write its record, ARRIVE (the last wave to arrive publishes the tile's bit
-//      count), pack (three branch-free ds_or_b32 per lane-row), publish the part's tail
-// Waiting happens only for: a tile number (scout), ring space / a free slot (resolution of older tiles).
+//   2  issue the loads of the next tile's part into the registers the lookups just vacated
+//   3  write the part's record and ARRIVE (the last wave to arrive publishes the tile's bit count)
+//   4  take the part's words in the ring, pack (three branch-free ds_or_b32 per lane-row), hand the part to the store
+//      wave (Smem::packed); the tile's last part also hands its last 31 bits to the next tile's record
+// Waiting happens only for: a tile number (scout), ring space / a free slot (the store wave, i.e. resolution of older
+// tiles).  The output is the store wave's business -- a data wave issues no store to the stream (the slow path aside).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm, int lane, int wave, bool permuted)
 {
@@ -834,57 +809,33 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
 #pragma unroll
     for (int r = 0; r < kRows; ++r) raw[r] = make_uint4(0, 0, 0, 0);
     uint32_t* const ring = sm.ring[wave];
-    WaveCtl c;
+    uint32_t n_loaded = 0, n_packed = 0, head = 0;           // workgroup-local tile indices: input loaded / part packed; ring: where the next part's words start
     uint32_t n_final = ~0u;
-    WS_DECL;
+    const uint32_t last_tile = (uint32_t)(p.num_tiles - 1);
 
-    // store the oldest packed part if its tile is resolved
-    auto try_store = [&]() -> int {      // 1 stored, 0 nothing to store, -1 abort
-        if (c.m_stored == c.m_packed) return 0;
-        if (lds_acq(&sm.n_resolved) <= c.m_stored) return 0;
-        if (!store_part(p, sm, ring, c.m_stored, wave, lane)) return -1;
-        ++c.m_stored;
-        if (lane == 0) lds_rel(&sm.stored[wave], c.m_stored);
-        if (c.m_stored == c.m_packed) c.head = 0;            // empty ring: start over at word 0
-        return 1;
-    };
-    // issue the loads of the workgroup's tile number c.m_loaded if the scout has drawn it
+    // issue the loads of the workgroup's tile number n_loaded if the scout has drawn it
     auto try_load = [&]() -> bool {
-        if (lds_acq(&sm.n_tickets) <= c.m_loaded) return false;
-        const uint32_t t = uni(sm.tq[c.m_loaded % kTq]);
-        load_tile(p, t, part_is_full(p, t, wave), wave, lane, raw);
-        ++c.m_loaded;
+        if (lds_acq(&sm.n_tickets) <= n_loaded) return false;
+        const uint32_t t = uni(sm.tq[n_loaded % kTq]);
+        load_tile(p, t, t != last_tile || part_is_full(p, t, wave), wave, lane, raw);
+        ++n_loaded;
         return true;
     };
 
     for (;;) {
         // ---- input of the next tile: normally prefetched; at the start and when the scout was behind, wait here
-        if (c.m_loaded == c.m_packed) {
+        if (n_loaded == n_packed) {
             WaveWait w;
             for (;;) {
                 if (n_final == ~0u) n_final = lds_rlx(&sm.n_final);      // (read BEFORE the ticket count: once set, every ticket is visible)
                 if (try_load()) break;
-                if (n_final != ~0u && c.m_loaded >= n_final) break;      // the tickets ran out
-                const int st = try_store();
-                if (st < 0) return;
-                if (st == 0 && !w.step(p, sm, lane)) return;
+                if (n_final != ~0u && n_loaded >= n_final) return;       // the tickets ran out: nothing left to encode
+                if (!w.step(p, sm, lane)) return;
             }
-            WS_LAP(kWsWaitTicket);
         }
-        if (c.m_loaded == c.m_packed) {                                   // nothing left to encode: store what is packed and leave
-            WaveWait w;
-            while (c.m_stored < c.m_packed) {
-                const int st = try_store();
-                if (st < 0) return;
-                if (st == 0 && !w.step(p, sm, lane)) return;
-            }
-            WS_LAP(kWsWaitDrain);
-            WS_DUMP(p, wave, lane);
-            return;
-        }
-        const uint32_t cur  = uni(sm.tq[c.m_packed % kTq]);
-        const uint32_t slot = c.m_packed % kSlots;
-        const bool full = part_is_full(p, cur, wave);        // (only the part the input ends in, and the empty ones behind it, are not)
+        const uint32_t cur  = uni(sm.tq[n_packed % kTq]);
+        const uint32_t slot = n_packed % kSlots;
+        const bool full = cur != last_tile || part_is_full(p, cur, wave);   // (only the part the input ends in, and the empty ones behind it, are not)
 
         // ---- 1: lookups, concatenation, scan (registers only)
         uint64_t acc[kRows];
@@ -922,27 +873,18 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             T         += (uint32_t)__builtin_amdgcn_readlane((int)incl[r], 63);
         }
 
-        WS_LAP(kWsEncode);
-        // ---- 2: the oldest part's stream stores, 3: the next tile's loads
-        if (try_store() < 0) return;
+        // ---- 2: the next tile's loads
         (void)try_load();
-        WS_LAP(kWsStore);
 
-        // ---- 4: slot, record, arrival, ring words
-        if (c.m_packed >= (uint32_t)kSlots) {                 // the slot's previous tile must be stored by every wave
-            const uint32_t floor_ = c.m_packed - (uint32_t)kSlots + 1u;
+        // ---- 3: slot, record, arrival
+        uint32_t freed = lds_acq(&sm.n_freed);
+        if (n_packed >= (uint32_t)kSlots + freed) {           // the slot's previous tile must have been stored
             WaveWait w;
-            for (;;) {
-                const uint32_t v = lane < kDataWaves ? __hip_atomic_load(&sm.stored[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : ~0u;
-                if (!__any(v < floor_)) break;
-                const int st = try_store();
-                if (st < 0) return;
-                if (st == 0 && !w.step(p, sm, lane)) return;
-            }
+            while (n_packed >= (uint32_t)kSlots + (freed = lds_acq(&sm.n_freed)))
+                if (!w.step(p, sm, lane)) return;
         }
-        WS_LAP(kWsWaitSlot);
-        const uint32_t need = (((T + 31u) >> 5) + 3u + 3u) & ~3u;    // carry word + data + the two words behind the data that pack / store touch
-        const bool slow = !full || need > kWaveRing;
+        const uint32_t need = ring_need(T);
+        const bool slow = !full || need > kWaveRing;          // (== !part_is_fast: the store wave's view of this part)
         if (lane == 0) {
             WaveRec& rec = sm.wrec[slot][wave];
             *reinterpret_cast<uint2*>(&rec.bits) = make_uint2(T, 0u);                        // bits; tail not known yet
@@ -955,36 +897,31 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         old = uni(old);
         if ((old >> 24) == (uint32_t)(kDataWaves - 1)) {
             // last to arrive: every part's base, the tile's bit count (what other workgroups wait for), slot counter reset
-            // (the lane number is taken afresh: kept live from the prologue, the per-lane record address it feeds was
-            // spilled to scratch and reloaded right here, on the path other workgroups wait for)
+            // (the lane number is taken afresh instead of kept live from the prologue)
             const int ln = lane_id_fresh();
             const uint32_t b    = ln < kDataWaves ? sm.wrec[slot][ln].bits : 0u;
-            const uint32_t incl = wave_incl_scan(b);
-            if (ln < kDataWaves) sm.wrec[slot][ln].base = incl - b;
-            const uint32_t Ttile = (uint32_t)__builtin_amdgcn_readlane((int)incl, kDataWaves - 1);
+            const uint32_t incb = wave_incl_scan(b);
+            if (ln < kDataWaves) sm.wrec[slot][ln].base = incb - b;
+            const uint32_t Ttile = (uint32_t)__builtin_amdgcn_readlane((int)incb, kDataWaves - 1);
             if (lane == 0) {
                 sm.ts[slot].arrive = 0u;
-                (void)__hip_atomic_fetch_max(&sm.n_bits_pub, c.m_packed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_max(&sm.n_bits_pub, n_packed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (cur != p.stall_tile) st_word(&p.bits32()[cur], kValid32 | Ttile);
             }
             TL(p, cur, 0, lane == 0);
         }
-        WS_LAP(kWsArrive);
-        uint32_t start = 0;
-        if (!slow) {
-            WaveWait w;
-            while ((start = ring_place(c, sm, wave, need)) == kNoRoom) {   // no room yet: store older parts until there is
-                const int st = try_store();
-                if (st < 0) return;
-                if (st == 0 && !w.step(p, sm, lane)) return;
-            }
-            c.head = start + need;
-        }
-        WS_LAP(kWsWaitRing);
-        if (lane == 0) *reinterpret_cast<uint2*>(&sm.wrec[slot][wave].start) = make_uint2(start, slow ? 0u : need);   // (read by this wave only)
 
-        // ---- 4b: pack
         if (!slow) {
+            // ---- 4: ring words, pack, hand over
+            uint32_t start;
+            if ((start = ring_place(sm, wave, head, n_packed, freed, need)) == kNoRoom) {
+                WaveWait w;
+                while ((start = ring_place(sm, wave, head, n_packed, lds_acq(&sm.n_freed), need)) == kNoRoom)
+                    if (!w.step(p, sm, lane)) return;
+            }
+            head = start + need;
+            if (lane == 0) *reinterpret_cast<uint2*>(&sm.wrec[slot][wave].start) = make_uint2(start, need);
+            zero_words(ring + start, need / 4u, lane);       // (what an older part left there; the store wave only reads)
             uint32_t* const st = ring + start + 1;
             if (!HVLC_DBG(p, kDbgNoPack)) {
                 const uint32_t longest = max(max(tot[0], tot[1]), max(tot[2], tot[3]));
@@ -1006,29 +943,324 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
                     }
                 }
             } else if (acc[0] + acc[1] + acc[2] + acc[3] == 0x123456789ull) st[incl[0] & 1023u] = tot[0];
-            if (T >= 31u)                                // the part's last 31 bits are all its own: publish the tail now
-                publish_tail<false>(p, sm, slot, wave, cur, extract_tail(st, T), lane);
-            ++c.m_packed;
-            WS_LAP(kWsPack); WS_COUNT(kWsTiles);
-        } else {
-            // slow path: the tail first if the part allows, then drain the ring, wait for this tile's offset, store the
-            // part directly
-            const bool tail_out = full && publish_slow_tail_early(p, sm, slot, wave, cur, lane, permuted);
-            ++c.m_packed;
-            WaveWait w;
-            while (c.m_stored + 1u < c.m_packed) {
-                const int st = try_store();
-                if (st < 0) return;
-                if (st == 0 && !w.step(p, sm, lane)) return;
+            // the tile's last part hands the stream's last 31 bits to the next tile (whose store wave may be waiting for
+            // nothing else) as soon as they exist; a shorter part's tail follows from the store wave
+            if (wave == kDataWaves - 1 && T >= 31u) {
+                const uint32_t tl = extract_tail(st, T);
+                if (lane == 0) st_word(&p.recs()[(uint64_t)cur + 1].tail, kValid32 | tl);
             }
-            while (lds_acq(&sm.n_resolved) < c.m_packed)
+            ++n_packed;
+            if (lane == 0) lds_rel(&sm.packed[wave], n_packed);
+        } else {
+            // slow path (cold): the tail first if the part allows, then wait until the ring is empty and this tile's offset
+            // is known, store the part directly
+            const bool tail_out = full && publish_slow_tail_early(p, sm, slot, wave, cur, lane, permuted);
+            if (lane == 0) *reinterpret_cast<uint2*>(&sm.wrec[slot][wave].start) = make_uint2(0u, 0u);
+            WaveWait w;
+            while (lds_acq(&sm.n_freed) < n_packed)          // every older tile stored: nothing of this wave is left in its ring
                 if (!w.step(p, sm, lane)) return;
-            if (!slow_part(p, sm, ring, c.m_packed - 1u, cur, wave, lane, permuted, tail_out)) return;
-            ++c.m_stored;
-            if (lane == 0) lds_rel(&sm.stored[wave], c.m_stored);
-            c.head = 0;
-            WS_LAP(kWsWaitSlow); WS_COUNT(kWsTiles);
+            while (lds_acq(&sm.n_resolved) <= n_packed)
+                if (!w.step(p, sm, lane)) return;
+            if (!slow_part(p, sm, ring, n_packed, cur, wave, lane, permuted, tail_out)) return;
+            ++n_packed;
+            if (lane == 0) lds_rel(&sm.packed[wave], n_packed);
+            head = 0;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// STORE wave: the only wave of a workgroup that writes the stream (slow parts aside).  Tile by tile, in the order the
+// scout resolves them: the segment offsets (one lane per segment, one store), then the tile's stretch of the stream.
+// Part w's words are global words [ow_w, ow_{w+1}) with ow_w = (tile offset + base_w) / 32: word g of part w is
+// alignbit(sb[k], sb[k + 1], s_w), k = g - ow_w, where sb[0] is the part's carry word (the 32 stream bits in front of
+// the part; the store wave takes them from the part in front as it goes) and sb[1..] the packed words.  The words are
+// stored in BLOCKS of 64 (256 bytes) aligned by address: one dword per lane, consecutive lanes read consecutive LDS
+// words (no bank conflicts).  The block in which part w ends and part w + 1 begins is stored once, its lanes fed from
+// two rings (a `junction`); only a tile's first and last block are partial, and a block next to a slow part.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t lane_value64(uint64_t v, uint32_t l);
+struct PartSrc {                 // where the words of a packed part come from (all wave-uniform)
+    const uint32_t* sb;          // carry word; sb[1 + j] = the part's own word j
+    uint64_t ow;                 // global index of the part's first word
+    uint32_t s;                  // global bit offset % 32
+    uint32_t need;               // ring words to zero once the part is stored
+};
+
+// The 32 stream bits that end where a part of T bits ends: its own last bits, preceded -- when it is shorter than
+// that -- by what its carry word holds (only the last 31 are ever used).
+__device__ __forceinline__ uint32_t carry_behind(const uint32_t* sb, uint32_t T)
+{
+    const uint32_t wi = T >> 5, sh = T & 31u;
+    const uint32_t hi = uni(sb[wi]), lo = uni(sb[wi + 1]);
+    return sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
+}
+
+// Words [g0, g1) of one part, g0 >= c.ow, any alignment, at most kBlockWords of them: one store instruction.
+__device__ __forceinline__ void store_piece(const EncodeParams& p, const PartSrc& c, uint64_t g0, uint64_t g1, int lane)
+{
+    const uint32_t k0 = (uint32_t)(g0 - c.ow), n = (uint32_t)(g1 - g0);
+    uint32_t* const dst = p.out + g0;
+    const uint32_t* const src = c.sb + k0;
+    if ((uint32_t)lane < n) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(src[lane], src[lane + 1], c.s), dst + lane);
+}
+
+// Store tile number n of the workgroup (resolved), part after part, every scalar fetched from LDS when it is needed:
+// the general form (slow parts, parts shorter than a word, the last tile).  False = abort.
+__device__ __forceinline__ bool store_tile_generic(const EncodeParams& p, Smem& sm, uint32_t n, int lane)
+{
+    const uint32_t slot = n % kSlots;
+    const uint32_t tile = uni(sm.tq[n % kTq]);
+    const uint64_t P    = uni64(sm.ts[slot].prefix);
+    uint32_t carry      = uni(sm.ts[slot].pred_tail);         // the (up to 31) stream bits in front of the next part
+    const bool last_tile = tile == (uint32_t)(p.num_tiles - 1);
+    // address alignment of the stream: block boundaries are words g with (g + mis) % 64 == 0
+    const uint32_t mis = (uint32_t)((uintptr_t)p.out >> 2) & (kBlockWords - 1u);
+    const uint64_t cap = p.out_cap;
+
+    // ---- segment offsets: lane l = segment l of the tile (parts' bases by the last arriver, rows by each data wave)
+    if (p.offsets && lane < kSegsPerTile && !HVLC_DBG(p, kDbgNoOffsets)) {
+        const WaveRec& r = sm.wrec[slot][lane / kRows];
+        const uint32_t rr = (uint32_t)lane % (uint32_t)kRows;
+        const uint32_t rel = r.base + (rr ? (&r.base)[rr] : 0u);
+        const uint64_t seg = (uint64_t)tile * kSegsPerTile + (uint64_t)lane;
+        if (seg < p.num_segs) __builtin_nontemporal_store(P + rel, &p.offsets[seg]);
+    }
+
+    PartSrc prev = { nullptr, 0, 0, 0 };
+    bool pend = false;               // prev's last, partial block [block start, prev's end) waits for the next part's first words
+    bool prev_fast = false;          // the part in front (of this tile) was a packed part: `carry` is mine to hand on
+    WaveWait w;
+#pragma unroll 1
+    for (int wv = 0; wv < kDataWaves; ++wv) {
+        const uint32_t T    = uni(sm.wrec[slot][wv].bits);
+        const uint64_t G    = P + (uint64_t)uni(sm.wrec[slot][wv].base);
+        if (!part_is_fast(p, tile, wv, T)) {
+            // ---- a slow part stores itself (cold): give its wave the tail in front of it, take the tail behind it
+            if (wv > 0 && prev_fast) {
+                if (lane == 0) lds_rel(&sm.wrec[slot][wv - 1].tail, kValid32 | (carry & 0x7fffffffu));
+                wake_workgroup();
+            }
+            for (;;) {
+                const uint32_t v = lds_acq(&sm.wrec[slot][wv].tail);
+                if (v & kValid32) { carry = v & 0x7fffffffu; break; }
+                if (!w.step(p, sm, lane)) return false;
+            }
+            prev_fast = false;
+            continue;
+        }
+        while (lds_acq(&sm.packed[wv]) <= n)                   // (normally packed long ago)
+            if (!w.step(p, sm, lane)) return false;
+        const uint2 sn = *reinterpret_cast<const uint2*>(&sm.wrec[slot][wv].start);
+        PartSrc c;
+        c.sb = sm.ring[wv] + uni(sn.x); c.need = uni(sn.y); c.ow = G >> 5; c.s = (uint32_t)G & 31u;
+        if (lane == 0) const_cast<uint32_t*>(c.sb)[0] = carry;  // carry word (same-wave LDS operations complete in order)
+
+        // the part's words: [lo, hi); the last part of the stream also stores the open word, zero padded, and the zero
+        // word cpu_vlc_encode leaves behind when the stream ends on a word boundary (cpuencode.cpp:39)
+        const bool last = last_tile && wv == kDataWaves - 1;
+        const uint64_t lo = c.ow;
+        uint64_t hi = (G + T) >> 5;
+        if (last) {
+            hi = (G + T + 31u) >> 5;
+            if (((G + T) & 31u) == 0u) hi += 1u;
+            if (lane == 0) {
+                p.result()[0] = G + T;
+                if (p.total_bits) *p.total_bits = G + T;
+            }
+        }
+        if (hi > cap) {                                          // capacity: decided per part, not per word
+            if (lane == 0) atomicOr(p.status(), kFlagCapacity);
+            hi = cap > lo ? cap : lo;
+        }
+        const bool more = wv + 1 < kDataWaves && hi == ((G + T) >> 5) &&
+                          part_is_fast(p, tile, wv + 1, uni(sm.wrec[slot][wv + 1].bits));   // the next part continues this one's last block
+        if (!HVLC_DBG(p, kDbgNoStore)) {
+            // first block: from the block boundary at or below lo
+            const uint64_t B0 = lo - (((uint32_t)lo + mis) & (kBlockWords - 1u));
+            const uint64_t e0 = hi < B0 + kBlockWords ? hi : B0 + kBlockWords;
+            if (pend) {
+                // junction: lanes below lo take prev's last words, the others this part's first words
+                const uint32_t nprev = (uint32_t)(lo - B0), nall = (uint32_t)(e0 - B0);
+                const bool isprev = (uint32_t)lane < nprev;
+                const uint32_t* src = isprev ? prev.sb + (uint32_t)(B0 - prev.ow) : c.sb - nprev;
+                const uint32_t  sh  = isprev ? prev.s : c.s;
+                if ((uint32_t)lane < nall)
+                    __builtin_nontemporal_store(__builtin_amdgcn_alignbit(src[lane], src[lane + 1], sh), p.out + B0 + lane);
+            } else if (e0 > lo) {
+                store_piece(p, c, lo, e0, lane);
+            }
+            // whole blocks
+            uint64_t B = B0 + kBlockWords;
+            if (B + kBlockWords <= hi) {
+                uint32_t* dst = p.out + B;
+                const uint32_t* src = c.sb + (uint32_t)(B - c.ow) + lane;
+                const uint32_t nblk = (uint32_t)((hi - B) / kBlockWords);
+#pragma unroll 1
+                for (uint32_t i = 0; i < nblk; ++i) {
+                    __builtin_nontemporal_store(__builtin_amdgcn_alignbit(src[0], src[1], c.s), dst + lane);
+                    src += kBlockWords; dst += kBlockWords;
+                }
+                B += (uint64_t)nblk * kBlockWords;
+            }
+            // last, partial block [B, hi): left to the next part if that continues it, else stored now
+            if (B < hi && B > lo && !more) store_piece(p, c, B, hi, lane);
+        }
+        carry = carry_behind(c.sb, T);
+        const uint64_t Bl = hi - (((uint32_t)hi + mis) & (kBlockWords - 1u));
+        pend = more && Bl > lo && Bl < hi && !HVLC_DBG(p, kDbgNoStore);
+        if (pend) prev = c;
+        prev_fast = true;
+        // the tile's last part: the next tile's record takes the tail now if the data wave could not give it at pack time
+        if (wv == kDataWaves - 1 && T < 31u && lane == 0)
+            st_word(&p.recs()[(uint64_t)tile + 1].tail, kValid32 | (carry & 0x7fffffffu));
+    }
+    return true;
+}
+
+
+// Store tile number n of the workgroup (resolved).  The common case -- ten packed parts of at least a word each, not
+// the stream's last tile -- keeps every part's record in the lane of the part's number (one vector read each), takes
+// its scalars from there with v_readlane and counts in words RELATIVE to the tile's first word (32-bit scalar
+// arithmetic); everything else goes through store_tile_generic.  The store wave is one serial instruction stream that
+// ten data waves wait for, and what it spends its time on is LDS round trips: per part, the reads of the block the part
+// starts in (a junction with the part in front, or the tile's ragged first block) and of its first four whole blocks
+// go out TOGETHER, then the shifts, then the stores.  The data waves zero their ring words themselves (when they take
+// them), so nothing is left to do behind the stores.  False = abort.
+__device__ __forceinline__ bool store_tile(const EncodeParams& p, Smem& sm, uint32_t n, int lane)
+{
+    const uint32_t slot = n % kSlots;
+    const uint32_t tile = uni(sm.tq[n % kTq]);
+    const int wvl = lane < kDataWaves ? lane : kDataWaves - 1;
+    const WaveRec& rec = sm.wrec[slot][wvl];
+    const uint32_t Tl = rec.bits, basel = rec.base;
+    uint32_t pk = __hip_atomic_load(&sm.packed[wvl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const bool plain = tile != (uint32_t)(p.num_tiles - 1) && Tl >= 32u && ring_need(Tl) <= kWaveRing;
+    if (!__all(plain)) return store_tile_generic(p, sm, n, lane);
+    const uint64_t P  = uni64(sm.ts[slot].prefix);
+    const uint32_t pt = uni(sm.ts[slot].pred_tail);
+    if (__any(pk <= n)) {                 // every part packed?  (normally long ago)
+        WaveWait w;
+        while (__any(__hip_atomic_load(&sm.packed[wvl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= n))
+            if (!w.step(p, sm, lane)) return false;
+    }
+#ifdef HVLC_ABL_SKIP_STORE
+    return true;                                                            // (tools/: what the data waves alone can do; wrong output)
+#endif
+    const uint32_t startl = rec.start;                                      // valid once packed
+    const uint64_t Gl = P + (uint64_t)basel;
+    const uint64_t Gend = lane_value64(Gl + Tl, kDataWaves - 1);
+    if ((Gend >> 5) > p.out_cap) return store_tile_generic(p, sm, n, lane);   // (capacity overrun: the general form reports it)
+    uint32_t* const sbl = &sm.ring[wvl][startl];
+    // the 32 stream bits behind every part (its own: it holds at least a word), handed to the part behind it as carry word
+    {
+        const uint32_t wi = Tl >> 5, sh = Tl & 31u;
+        const uint32_t hi = sbl[wi], lo = sbl[wi + 1];
+        const uint32_t cout = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
+        uint32_t cin = (uint32_t)__shfl_up((int)cout, 1);
+        if (lane == 0) cin = pt;
+        if (lane < kDataWaves) sbl[0] = cin;
+    }
+    // segment offsets: lane l = segment l of the tile
+    if (p.offsets && lane < kSegsPerTile && !HVLC_DBG(p, kDbgNoOffsets)) {
+        const WaveRec& r = sm.wrec[slot][lane / kRows];
+        const uint32_t rr = (uint32_t)lane % (uint32_t)kRows;
+        const uint32_t rel = r.base + (rr ? (&r.base)[rr] : 0u);
+        __builtin_nontemporal_store(P + rel, &p.offsets[(uint64_t)tile * kSegsPerTile + (uint64_t)lane]);
+    }
+    if (HVLC_DBG(p, kDbgNoStore)) return true;
+    // ---- the stream: positions in words relative to the tile's first word ow0
+    const uint64_t ow0  = P >> 5;                                           // (base of part 0 is 0)
+    uint32_t* const outp = p.out + ow0;
+    const uint32_t mis0 = ((uint32_t)((uintptr_t)p.out >> 2) + (uint32_t)ow0) & (kBlockWords - 1u);   // block boundaries: r with (r + mis0) % 64 == 0
+    const int32_t  rl   = (int32_t)(uint32_t)((Gl >> 5) - ow0);             // the part's first word
+    const uint32_t sl   = (uint32_t)Gl & 31u;
+    const int32_t  rend = (int32_t)(uint32_t)((Gend >> 5) - ow0);
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t sbaddr = (uint32_t)(uintptr_t)(lds_u32*)sbl;             // LDS byte address of the part's carry word
+    auto lds_at = [](uint32_t byte_addr) { return (const uint32_t*)(lds_u32*)(uintptr_t)byte_addr; };
+
+    int32_t lo = 0;                                                         // part 0 starts at relative word 0
+    uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)sbaddr, 0), sh = (uint32_t)__builtin_amdgcn_readlane((int)sl, 0);
+    uint32_t psb = 0, psh = 0; int32_t plo = 0;                             // the part in front, while its last block is pending
+    bool pend = false;
+#pragma unroll 1
+    for (int wv = 0; wv < kDataWaves; ++wv) {
+        const bool more = wv + 1 < kDataWaves;
+        int32_t hi = rend; uint32_t nsb = 0, nsh = 0;
+        if (more) {
+            hi  = __builtin_amdgcn_readlane(rl, wv + 1);
+            nsb = (uint32_t)__builtin_amdgcn_readlane((int)sbaddr, wv + 1);
+            nsh = (uint32_t)__builtin_amdgcn_readlane((int)sl, wv + 1);
+        }
+        // block 0 = the block the part starts in: [B0, B0 + 64); its whole blocks follow
+        const int32_t B0 = lo - (int32_t)(((uint32_t)lo + mis0) & (kBlockWords - 1u));
+        const int32_t e0 = hi < B0 + 64 ? hi : B0 + 64;
+        const int32_t nblk = hi >= B0 + 128 ? (hi - (B0 + 64)) / 64 : 0;    // whole blocks behind block 0
+        // -- all reads of block 0 and of the first four whole blocks
+        const int32_t k0 = B0 + lane;                                       // lane's word in block 0
+        const bool isprev = pend && k0 < lo;
+        const uint32_t a_addr = (isprev ? psb + (uint32_t)(k0 - plo) * 4u : sb + (uint32_t)(k0 - lo) * 4u);
+        const uint32_t a_sh   = isprev ? psh : sh;
+        const uint32_t* const pa = lds_at(a_addr);
+        const uint32_t* const pw = lds_at(sb + (uint32_t)(B0 + 64 - lo + lane) * 4u);
+        const uint32_t a0 = pa[0], a1 = pa[1];
+        const uint32_t b0 = pw[0], b1 = pw[1], c0 = pw[64], c1 = pw[65], d0 = pw[128], d1 = pw[129], f0 = pw[192], f1 = pw[193];
+        uint32_t* const dst = outp + B0;                                    // (scalar; part 0's B0 may lie below the tile: those lanes are masked)
+        const int32_t first = pend ? B0 : lo;
+        if (k0 >= first && k0 < e0) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(a0, a1, a_sh), dst + lane);
+        if (nblk >= 1) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(b0, b1, sh), dst + 64 + lane);
+        if (nblk >= 2) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(c0, c1, sh), dst + 128 + lane);
+        if (nblk >= 3) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(d0, d1, sh), dst + 192 + lane);
+        if (nblk >= 4) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(f0, f1, sh), dst + 256 + lane);
+        if (nblk > 4) {                                                     // (more than ~1.3 KiB per part: 3 bits per symbol and up)
+            const uint32_t* src = lds_at(sb + (uint32_t)(B0 + 320 - lo + lane) * 4u);
+            uint32_t* d2 = dst + 320;
+            int32_t i = 4;
+#pragma unroll 1
+            for (; i + 4 <= nblk; i += 4) {
+                const uint32_t q0 = src[0], q1 = src[1], r0 = src[64], r1 = src[65], t0 = src[128], t1 = src[129], u0 = src[192], u1 = src[193];
+                __builtin_nontemporal_store(__builtin_amdgcn_alignbit(q0, q1, sh), d2 + lane);
+                __builtin_nontemporal_store(__builtin_amdgcn_alignbit(r0, r1, sh), d2 + 64 + lane);
+                __builtin_nontemporal_store(__builtin_amdgcn_alignbit(t0, t1, sh), d2 + 128 + lane);
+                __builtin_nontemporal_store(__builtin_amdgcn_alignbit(u0, u1, sh), d2 + 192 + lane);
+                src += 256; d2 += 256;
+            }
+#pragma unroll 1
+            for (; i < nblk; ++i) {
+                __builtin_nontemporal_store(__builtin_amdgcn_alignbit(src[0], src[1], sh), d2 + lane);
+                src += 64; d2 += 64;
+            }
+        }
+        // the part's last, partial block [Bl, hi): left to the part behind it (a junction) when there is one and the block
+        // lies behind block 0; the tile's last part stores it
+        const int32_t Bl = hi - (int32_t)(((uint32_t)hi + mis0) & (kBlockWords - 1u));
+        pend = more && Bl > B0 && Bl < hi;
+        if (!more && Bl > B0 && Bl < hi) {
+            const uint32_t* ps = lds_at(sb + (uint32_t)(Bl - lo + lane) * 4u);
+            if (Bl + lane < hi) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(ps[0], ps[1], sh), outp + Bl + lane);
+        }
+        plo = lo; psb = sb; psh = sh;
+        lo = hi; sb = nsb; sh = nsh;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void encode_store_wave(const EncodeParams& p, Smem& sm, int lane)
+{
+    uint32_t n = 0, n_final = ~0u;
+    for (;;) {
+        WaveWait w;
+        for (;;) {
+            if (lds_acq(&sm.n_resolved) > n) break;
+            if (n_final == ~0u) n_final = lds_rlx(&sm.n_final);
+            if (n_final != ~0u && n >= n_final) return;
+            if (!w.step(p, sm, lane)) return;
+        }
+        if (!store_tile(p, sm, n, lane)) return;
+        ++n;
+        if (lane == 0) lds_rel(&sm.n_freed, n);
+        wake_workgroup();                                      // a data wave may be waiting for ring space or a slot
     }
 }
 
@@ -1369,8 +1601,14 @@ k_encode(EncodeParams p)
 #ifdef HVLC_PRIO_SCOUT
         if (wave == kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_SCOUT);
 #endif
-        if (wave == kDataWaves) encode_scout_wave(p, sm, lane, first_ticket);
-        else                    encode_data_wave(p, sm, lane, wave, permuted);
+        if (wave == kDataWaves)          encode_scout_wave(p, sm, lane, first_ticket);
+        else if (wave == kDataWaves + 1) {
+#ifndef HVLC_NO_STORE_PRIO
+            __builtin_amdgcn_s_setprio(3);       // one short, serial instruction stream that ten data waves wait for
+#endif
+            encode_store_wave(p, sm, lane);
+        }
+        else                             encode_data_wave(p, sm, lane, wave, permuted);
     }
 
     // ---- every wave of the grid leaves through here, finished or giving up; the last wave of a workgroup reports for all
