@@ -205,6 +205,17 @@ __device__ __forceinline__ uint64_t uni64(uint64_t x)
     return ((uint64_t)uni((uint32_t)(x >> 32)) << 32) | (uint64_t)uni((uint32_t)x);
 }
 
+// The lane number, recomputed where it is called (two VALU instructions) instead of kept in a register from the prologue --
+// and, being volatile, not an invariant the compiler could hoist out of a loop together with everything computed from it:
+// cold paths take their lane number from here, or their per-lane addresses and masks end up in (spilled) registers of
+// the hot loop around them.
+__device__ __forceinline__ int lane_id_fresh()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 __device__ __forceinline__ void st_word(uint32_t* p, uint32_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -365,7 +376,6 @@ __device__ __forceinline__ void encode16(const uint4& v, const uint2* lut, uint6
         tot = (tot + e3.y) + (e2.y + e1.y + e0.y);
     }
 }
-
 // The hot-path form: the <=64 bits of `acc` (right-aligned, nothing above them) END at part-local bit e (exclusive);
 // always three ORs, no per-lane branches, no left-alignment: with r = e % 32 and W = e / 32 the words W-2, W-1, W
 // take hi >> r, {hi,lo} >> r and lo << (32-r).  Words in front of the string (down to two words in front of st[0])
@@ -551,9 +561,10 @@ __device__ __forceinline__ void load_tile(const EncodeParams& p, uint32_t tile, 
         }
     } else {
         const uint32_t* in32 = (const uint32_t*)p.in;
+        const int cl = lane_id_fresh();      // (cold: not to be hoisted out of the data wave's loop)
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
-            const uint64_t wbase = (uint64_t)tile * kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
+            const uint64_t wbase = (uint64_t)tile * kTileWords + (uint64_t)((wave * kRows + r) * 64 + cl) * 4u;
             raw[r].x = wbase + 0 < p.num_words ? in32[wbase + 0] : 0u;
             raw[r].y = wbase + 1 < p.num_words ? in32[wbase + 1] : 0u;
             raw[r].z = wbase + 2 < p.num_words ? in32[wbase + 2] : 0u;
@@ -599,13 +610,6 @@ __device__ __forceinline__ void zero_words(uint32_t* base, uint32_t n_vec4, int 
     for (uint32_t i = (uint32_t)lane; i < n_vec4; i += 64u) z[i] = make_uint4(0, 0, 0, 0);
 }
 
-// The lane number, recomputed where it is called (two VALU instructions) instead of kept in a register from the prologue.
-__device__ __forceinline__ int lane_id_fresh()
-{
-    int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-}
 // LDS words shared between the waves of a workgroup: relaxed / acquire / release at WORKGROUP scope (LDS
 // operations of one wave complete in order; the scopes only keep the compiler from reordering them).
 __device__ __forceinline__ uint32_t lds_acq(const uint32_t* p) { return uni(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
@@ -685,8 +689,9 @@ __device__ __forceinline__ bool pred_tail_of(const EncodeParams& p, Smem& sm, ui
 // byte) otherwise runs one part at a time, each waiting for the tail of the one in front.  False: the last segment
 // holds fewer than 31 bits (zero-length codes), the tail follows when the part is stored.
 __device__ __forceinline__ bool publish_slow_tail_early(const EncodeParams& p, Smem& sm, uint32_t slot, int wave, uint32_t tile,
-                                                        int lane, bool permuted)
+                                                        int /*lane*/, bool permuted)
 {
+    const int lane = lane_id_fresh();      // cold code: nothing here may be hoisted into the data wave's loop as an invariant
     const uint64_t seg = (uint64_t)tile * kSegsPerTile + (uint64_t)(wave * kRows + (kRows - 1));
     const uint4 v = ((const uint4*)p.in)[seg * (kSegWords / 4u) + (uint64_t)lane];
     const uint32_t w[4] = { v.x, v.y, v.z, v.w };
@@ -722,8 +727,9 @@ __device__ __forceinline__ bool publish_slow_tail_early(const EncodeParams& p, S
 // taken as one buffer, funnel-shifted and stored; the carry runs through the segments exactly as it runs through
 // parts.  Leaves the ring zeroed.  `tail_published`: publish_slow_tail_early has done its work.
 __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint32_t* ring, uint32_t j, uint32_t tile,
-                                          int wave, int lane, bool permuted, bool tail_published)
+                                          int wave, int /*lane*/, bool permuted, bool tail_published)
 {
+    const int lane = lane_id_fresh();      // cold code: see publish_slow_tail_early
     const uint32_t slot = j % kSlots;
     uint64_t G = uni64(sm.ts[slot].prefix) + (uint64_t)uni(sm.wrec[slot][wave].base);
     uint32_t carry = 0;
@@ -841,6 +847,8 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         uint64_t acc[kRows];
         uint32_t tot[kRows], incl[kRows], rowbase[kRows];
         if (full) {
+            // (row after row: the four rows advanced together, with the next step's table entries requested ahead --
+            // eight to twelve LDS reads in flight instead of four -- took 5 % MORE time: tools/ab.py, round 3)
             if (permuted) {
 #pragma unroll
                 for (int r = 0; r < kRows; ++r) encode16<true>(raw[r], sm.lut, acc[r], tot[r]);
@@ -850,9 +858,10 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             }
         } else {
             // the part the input ends in (or an empty one behind it): bit counts only, the slow path packs it (cold code)
+            const int cl = lane_id_fresh();
 #pragma unroll
             for (int r = 0; r < kRows; ++r) {
-                const uint64_t wbase = (uint64_t)cur * kTileWords + (uint64_t)((wave * kRows + r) * 64 + lane) * 4u;
+                const uint64_t wbase = (uint64_t)cur * kTileWords + (uint64_t)((wave * kRows + r) * 64 + cl) * 4u;
                 const int nv = valid_words(p, wbase);
                 const uint32_t wd[4] = { raw[r].x, raw[r].y, raw[r].z, raw[r].w };
                 uint32_t t = 0;
@@ -933,12 +942,13 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
                     // a row (L2) and pack it pairwise
 #pragma unroll
                     for (int r = 0; r < kRows; ++r) put_bits64_end(st, rowbase[r] + incl[r], tot[r] <= 64u ? acc[r] : 0ull);
+                    const int cl = lane_id_fresh();
 #pragma unroll
                     for (int r = 0; r < kRows; ++r) {
                         if (tot[r] > 64u) {
                             const char* base = (const char*)p.in + (uint64_t)cur * (uint64_t)(kTileWords * 4);
                             put_row_pairs_mem(st, rowbase[r] + incl[r] - tot[r],
-                                              (const uint32_t*)(base + (uint32_t)((wave * kRows + r) * 64 + lane) * 16u), sm.lut, permuted);
+                                              (const uint32_t*)(base + (uint32_t)((wave * kRows + r) * 64 + cl) * 16u), sm.lut, permuted);
                         }
                     }
                 }
@@ -1007,8 +1017,9 @@ __device__ __forceinline__ void store_piece(const EncodeParams& p, const PartSrc
 
 // Store tile number n of the workgroup (resolved), part after part, every scalar fetched from LDS when it is needed:
 // the general form (slow parts, parts shorter than a word, the last tile).  False = abort.
-__device__ __forceinline__ bool store_tile_generic(const EncodeParams& p, Smem& sm, uint32_t n, int lane)
+__device__ __forceinline__ bool store_tile_generic(const EncodeParams& p, Smem& sm, uint32_t n, int /*lane*/)
 {
+    const int lane = lane_id_fresh();      // cold code: see publish_slow_tail_early
     const uint32_t slot = n % kSlots;
     const uint32_t tile = uni(sm.tq[n % kTq]);
     const uint64_t P    = uni64(sm.ts[slot].prefix);
