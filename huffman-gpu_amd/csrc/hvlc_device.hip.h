@@ -134,7 +134,7 @@ struct EncodeParams {
     uint32_t        stall_tile;      // TEST HOOK: this tile's bit count is never published (~0: none); see hvlc_api.hip
     uint32_t        dbg;             // ablation flags, honoured only in -DHVLC_EXPERIMENT builds (tools/)
     uint64_t*       dbg_tl;          // per-tile timeline [tiles][8] (100 MHz ticks), -DHVLC_EXPERIMENT builds only
-    uint64_t*       dbg_ws;          // per-wave time accounting [grid][8 waves][16] (shader clocks), -DHVLC_EXPERIMENT builds only
+    uint64_t*       dbg_ws;          // per-wave time accounting [grid][16 waves][16] (shader clocks), -DHVLC_EXPERIMENT builds only
 
     __device__ __forceinline__ uint32_t* ctl() const { return (uint32_t*)ws; }
     __device__ __forceinline__ uint32_t* status() const { return (uint32_t*)ws + (scan ? kCtlScanStatus : half); }   // flag word (atomic RMWs only)
@@ -167,7 +167,7 @@ struct WaveStats {
     __device__ __forceinline__ void lap(int i) { const uint64_t now = __builtin_amdgcn_s_memtime(); t[i] += now - last; last = now; }
     __device__ __forceinline__ void dump(uint64_t* buf, int wave) {
         t[kWsTotal] = __builtin_amdgcn_s_memtime() - t[kWsTotal];
-        if (buf) for (int i = 0; i < 16; ++i) buf[((uint64_t)blockIdx.x * 8 + wave) * 16 + i] = t[i];
+        if (buf) for (int i = 0; i < 16; ++i) buf[((uint64_t)blockIdx.x * 16 + wave) * 16 + i] = t[i];
     }
 };
 #define WS_DECL WaveStats ws; ws.init()
@@ -818,6 +818,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
     uint32_t n_loaded = 0, n_packed = 0, head = 0;           // workgroup-local tile indices: input loaded / part packed; ring: where the next part's words start
     uint32_t n_final = ~0u;
     const uint32_t last_tile = (uint32_t)(p.num_tiles - 1);
+    WS_DECL;
 
     // issue the loads of the workgroup's tile number n_loaded if the scout has drawn it
     auto try_load = [&]() -> bool {
@@ -835,9 +836,10 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             for (;;) {
                 if (n_final == ~0u) n_final = lds_rlx(&sm.n_final);      // (read BEFORE the ticket count: once set, every ticket is visible)
                 if (try_load()) break;
-                if (n_final != ~0u && n_loaded >= n_final) return;       // the tickets ran out: nothing left to encode
+                if (n_final != ~0u && n_loaded >= n_final) { WS_LAP(kWsWaitTicket); WS_DUMP(p, wave, lane); return; }   // the tickets ran out: nothing left to encode
                 if (!w.step(p, sm, lane)) return;
             }
+            WS_LAP(kWsWaitTicket);
         }
         const uint32_t cur  = uni(sm.tq[n_packed % kTq]);
         const uint32_t slot = n_packed % kSlots;
@@ -882,8 +884,10 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             T         += (uint32_t)__builtin_amdgcn_readlane((int)incl[r], 63);
         }
 
+        WS_LAP(kWsEncode);
         // ---- 2: the next tile's loads
         (void)try_load();
+        WS_LAP(kWsStore);
 
         // ---- 3: slot, record, arrival
         uint32_t freed = lds_acq(&sm.n_freed);
@@ -892,6 +896,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             while (n_packed >= (uint32_t)kSlots + (freed = lds_acq(&sm.n_freed)))
                 if (!w.step(p, sm, lane)) return;
         }
+        WS_LAP(kWsWaitSlot);
         const uint32_t need = ring_need(T);
         const bool slow = !full || need > kWaveRing;          // (== !part_is_fast: the store wave's view of this part)
         if (lane == 0) {
@@ -920,6 +925,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             TL(p, cur, 0, lane == 0);
         }
 
+        WS_LAP(kWsArrive);
         if (!slow) {
             // ---- 4: ring words, pack, hand over
             uint32_t start;
@@ -928,6 +934,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
                 while ((start = ring_place(sm, wave, head, n_packed, lds_acq(&sm.n_freed), need)) == kNoRoom)
                     if (!w.step(p, sm, lane)) return;
             }
+            WS_LAP(kWsWaitRing);
             head = start + need;
             if (lane == 0) *reinterpret_cast<uint2*>(&sm.wrec[slot][wave].start) = make_uint2(start, need);
             zero_words(ring + start, need / 4u, lane);       // (what an older part left there; the store wave only reads)
@@ -961,6 +968,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             }
             ++n_packed;
             if (lane == 0) lds_rel(&sm.packed[wave], n_packed);
+            WS_LAP(kWsPack); WS_COUNT(kWsTiles);
         } else {
             // slow path (cold): the tail first if the part allows, then wait until the ring is empty and this tile's offset
             // is known, store the part directly
@@ -1130,6 +1138,11 @@ __device__ __forceinline__ bool store_tile_generic(const EncodeParams& p, Smem& 
 }
 
 
+#ifdef HVLC_ABL_NO_GLOBAL_STORE
+#define ABL_STORE(v, ptr) do { auto v_ = (v); asm volatile("" :: "v"(v_)); (void)(ptr); } while (0)   // (tools/: the store wave's work without its memory traffic)
+#else
+#define ABL_STORE(v, ptr) __builtin_nontemporal_store(v, ptr)
+#endif
 // Store tile number n of the workgroup (resolved).  The common case -- ten packed parts of at least a word each, not
 // the stream's last tile -- keeps every part's record in the lane of the part's number (one vector read each), takes
 // its scalars from there with v_readlane and counts in words RELATIVE to the tile's first word (32-bit scalar
@@ -1177,7 +1190,7 @@ __device__ __forceinline__ bool store_tile(const EncodeParams& p, Smem& sm, uint
         const WaveRec& r = sm.wrec[slot][lane / kRows];
         const uint32_t rr = (uint32_t)lane % (uint32_t)kRows;
         const uint32_t rel = r.base + (rr ? (&r.base)[rr] : 0u);
-        __builtin_nontemporal_store(P + rel, &p.offsets[(uint64_t)tile * kSegsPerTile + (uint64_t)lane]);
+        ABL_STORE(P + rel, &p.offsets[(uint64_t)tile * kSegsPerTile + (uint64_t)lane]);
     }
     if (HVLC_DBG(p, kDbgNoStore)) return true;
     // ---- the stream: positions in words relative to the tile's first word ow0
@@ -1191,68 +1204,81 @@ __device__ __forceinline__ bool store_tile(const EncodeParams& p, Smem& sm, uint
     const uint32_t sbaddr = (uint32_t)(uintptr_t)(lds_u32*)sbl;             // LDS byte address of the part's carry word
     auto lds_at = [](uint32_t byte_addr) { return (const uint32_t*)(lds_u32*)(uintptr_t)byte_addr; };
 
-    int32_t lo = 0;                                                         // part 0 starts at relative word 0
-    uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)sbaddr, 0), sh = (uint32_t)__builtin_amdgcn_readlane((int)sl, 0);
-    uint32_t psb = 0, psh = 0; int32_t plo = 0;                             // the part in front, while its last block is pending
-    bool pend = false;
-#pragma unroll 1
-    for (int wv = 0; wv < kDataWaves; ++wv) {
-        const bool more = wv + 1 < kDataWaves;
-        int32_t hi = rend; uint32_t nsb = 0, nsh = 0;
-        if (more) {
-            hi  = __builtin_amdgcn_readlane(rl, wv + 1);
-            nsb = (uint32_t)__builtin_amdgcn_readlane((int)sbaddr, wv + 1);
-            nsh = (uint32_t)__builtin_amdgcn_readlane((int)sl, wv + 1);
-        }
-        // block 0 = the block the part starts in: [B0, B0 + 64); its whole blocks follow
-        const int32_t B0 = lo - (int32_t)(((uint32_t)lo + mis0) & (kBlockWords - 1u));
-        const int32_t e0 = hi < B0 + 64 ? hi : B0 + 64;
-        const int32_t nblk = hi >= B0 + 128 ? (hi - (B0 + 64)) / 64 : 0;    // whole blocks behind block 0
-        // -- all reads of block 0 and of the first four whole blocks
-        const int32_t k0 = B0 + lane;                                       // lane's word in block 0
+    // ---- software pipeline over the parts: the LDS reads of part w + 1 (the block it starts in -- a junction with part
+    // w when w leaves its last block pending -- and up to eight whole blocks) are issued BEFORE the shifts and stores of
+    // part w; left to itself the wave waits out an LDS round trip per part (ten per tile, ~800 clocks each under load).
+    struct Batch {
+        int32_t lo, hi, B0, e0, nblk, first; uint32_t sb, sh;               // scalars
+        uint32_t a0, a1, a_sh;                                              // block 0 (per lane: it may be fed from two parts)
+        uint32_t w[16];                                                     // whole blocks 1..8: word pairs
+    };
+    int32_t plo = 0; uint32_t psb = 0, psh = 0; bool pend = false;           // the part in front, while its last block is pending
+    auto issue = [&](int wv, int32_t lo, Batch& q) {
+        q.lo = lo;
+        q.sb = (uint32_t)__builtin_amdgcn_readlane((int)sbaddr, wv);
+        q.sh = (uint32_t)__builtin_amdgcn_readlane((int)sl, wv);
+        q.hi = wv + 1 < kDataWaves ? __builtin_amdgcn_readlane(rl, wv + 1) : rend;
+        q.B0 = lo - (int32_t)(((uint32_t)lo + mis0) & (kBlockWords - 1u));  // block 0 = the block the part starts in: [B0, B0 + 64)
+        q.e0 = q.hi < q.B0 + 64 ? q.hi : q.B0 + 64;
+        q.nblk = q.hi >= q.B0 + 128 ? (q.hi - (q.B0 + 64)) / 64 : 0;        // whole blocks behind block 0
+        q.first = pend ? q.B0 : lo;
+        const int32_t k0 = q.B0 + lane;                                     // lane's word in block 0
         const bool isprev = pend && k0 < lo;
-        const uint32_t a_addr = (isprev ? psb + (uint32_t)(k0 - plo) * 4u : sb + (uint32_t)(k0 - lo) * 4u);
-        const uint32_t a_sh   = isprev ? psh : sh;
-        const uint32_t* const pa = lds_at(a_addr);
-        const uint32_t* const pw = lds_at(sb + (uint32_t)(B0 + 64 - lo + lane) * 4u);
-        const uint32_t a0 = pa[0], a1 = pa[1];
-        const uint32_t b0 = pw[0], b1 = pw[1], c0 = pw[64], c1 = pw[65], d0 = pw[128], d1 = pw[129], f0 = pw[192], f1 = pw[193];
-        uint32_t* const dst = outp + B0;                                    // (scalar; part 0's B0 may lie below the tile: those lanes are masked)
-        const int32_t first = pend ? B0 : lo;
-        if (k0 >= first && k0 < e0) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(a0, a1, a_sh), dst + lane);
-        if (nblk >= 1) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(b0, b1, sh), dst + 64 + lane);
-        if (nblk >= 2) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(c0, c1, sh), dst + 128 + lane);
-        if (nblk >= 3) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(d0, d1, sh), dst + 192 + lane);
-        if (nblk >= 4) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(f0, f1, sh), dst + 256 + lane);
-        if (nblk > 4) {                                                     // (more than ~1.3 KiB per part: 3 bits per symbol and up)
-            const uint32_t* src = lds_at(sb + (uint32_t)(B0 + 320 - lo + lane) * 4u);
-            uint32_t* d2 = dst + 320;
-            int32_t i = 4;
+        const uint32_t* const pa = lds_at(isprev ? psb + (uint32_t)(k0 - plo) * 4u : q.sb + (uint32_t)(k0 - lo) * 4u);
+        q.a_sh = isprev ? psh : q.sh;
+        q.a0 = pa[0]; q.a1 = pa[1];
+        const uint32_t* const pw = lds_at(q.sb + (uint32_t)(q.B0 + 64 - lo + lane) * 4u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { q.w[2 * j] = pw[64 * j]; q.w[2 * j + 1] = pw[64 * j + 1]; }
+        if (q.nblk > 4) {
+#pragma unroll
+            for (int j = 4; j < 8; ++j) { q.w[2 * j] = pw[64 * j]; q.w[2 * j + 1] = pw[64 * j + 1]; }
+        }
+        // the part's last, partial block [Bl, hi) is left to the part behind it (a junction) when there is one and the
+        // block lies behind block 0
+        const int32_t Bl = q.hi - (int32_t)(((uint32_t)q.hi + mis0) & (kBlockWords - 1u));
+        pend = wv + 1 < kDataWaves && Bl > q.B0 && Bl < q.hi;
+        plo = lo; psb = q.sb; psh = q.sh;
+    };
+    auto consume = [&](const Batch& c, bool more) {
+        uint32_t* const dst = outp + c.B0;                                  // (scalar; part 0's B0 may lie below the tile: those lanes are masked)
+        const int32_t k0 = c.B0 + lane;
+        if (k0 >= c.first && k0 < c.e0) ABL_STORE(__builtin_amdgcn_alignbit(c.a0, c.a1, c.a_sh), dst + lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c.nblk > j) ABL_STORE(__builtin_amdgcn_alignbit(c.w[2 * j], c.w[2 * j + 1], c.sh), dst + 64 * (j + 1) + lane);
+        if (c.nblk > 4) {
+#pragma unroll
+            for (int j = 4; j < 8; ++j)
+                if (c.nblk > j) ABL_STORE(__builtin_amdgcn_alignbit(c.w[2 * j], c.w[2 * j + 1], c.sh), dst + 64 * (j + 1) + lane);
+            if (c.nblk > 8) {                                               // (more than 2.3 KiB per part: 4.6 bits per symbol and up)
+                const uint32_t* src = lds_at(c.sb + (uint32_t)(c.B0 + 576 - c.lo + lane) * 4u);
+                uint32_t* d2 = dst + 576;
 #pragma unroll 1
-            for (; i + 4 <= nblk; i += 4) {
-                const uint32_t q0 = src[0], q1 = src[1], r0 = src[64], r1 = src[65], t0 = src[128], t1 = src[129], u0 = src[192], u1 = src[193];
-                __builtin_nontemporal_store(__builtin_amdgcn_alignbit(q0, q1, sh), d2 + lane);
-                __builtin_nontemporal_store(__builtin_amdgcn_alignbit(r0, r1, sh), d2 + 64 + lane);
-                __builtin_nontemporal_store(__builtin_amdgcn_alignbit(t0, t1, sh), d2 + 128 + lane);
-                __builtin_nontemporal_store(__builtin_amdgcn_alignbit(u0, u1, sh), d2 + 192 + lane);
-                src += 256; d2 += 256;
-            }
-#pragma unroll 1
-            for (; i < nblk; ++i) {
-                __builtin_nontemporal_store(__builtin_amdgcn_alignbit(src[0], src[1], sh), d2 + lane);
-                src += 64; d2 += 64;
+                for (int32_t i = 8; i < c.nblk; ++i) {
+                    ABL_STORE(__builtin_amdgcn_alignbit(src[0], src[1], c.sh), d2 + lane);
+                    src += 64; d2 += 64;
+                }
             }
         }
-        // the part's last, partial block [Bl, hi): left to the part behind it (a junction) when there is one and the block
-        // lies behind block 0; the tile's last part stores it
-        const int32_t Bl = hi - (int32_t)(((uint32_t)hi + mis0) & (kBlockWords - 1u));
-        pend = more && Bl > B0 && Bl < hi;
-        if (!more && Bl > B0 && Bl < hi) {
-            const uint32_t* ps = lds_at(sb + (uint32_t)(Bl - lo + lane) * 4u);
-            if (Bl + lane < hi) __builtin_nontemporal_store(__builtin_amdgcn_alignbit(ps[0], ps[1], sh), outp + Bl + lane);
+        if (!more) {                                                        // the tile's last part stores its last, partial block itself
+            const int32_t Bl = c.hi - (int32_t)(((uint32_t)c.hi + mis0) & (kBlockWords - 1u));
+            if (Bl > c.B0 && Bl < c.hi) {
+                const uint32_t* ps = lds_at(c.sb + (uint32_t)(Bl - c.lo + lane) * 4u);
+                if (Bl + lane < c.hi) ABL_STORE(__builtin_amdgcn_alignbit(ps[0], ps[1], c.sh), outp + Bl + lane);
+            }
         }
-        plo = lo; psb = sb; psh = sh;
-        lo = hi; sb = nsb; sh = nsh;
+    };
+    static_assert(kDataWaves % 2 == 0, "two register sets take turns");
+    Batch A, B;
+    issue(0, 0, A);
+#pragma unroll 1
+    for (int wv = 0; wv < kDataWaves; wv += 2) {
+        issue(wv + 1, A.hi, B);
+        consume(A, true);
+        const bool more = wv + 2 < kDataWaves;
+        if (more) issue(wv + 2, B.hi, A);
+        consume(B, more);
     }
     return true;
 }
@@ -1260,15 +1286,20 @@ __device__ __forceinline__ bool store_tile(const EncodeParams& p, Smem& sm, uint
 __device__ __forceinline__ void encode_store_wave(const EncodeParams& p, Smem& sm, int lane)
 {
     uint32_t n = 0, n_final = ~0u;
+    WS_DECL;
     for (;;) {
         WaveWait w;
         for (;;) {
             if (lds_acq(&sm.n_resolved) > n) break;
             if (n_final == ~0u) n_final = lds_rlx(&sm.n_final);
-            if (n_final != ~0u && n >= n_final) return;
+            if (n_final != ~0u && n >= n_final) { WS_LAP(kWsWaitTicket); WS_DUMP(p, kDataWaves + 1, lane); return; }
             if (!w.step(p, sm, lane)) return;
         }
+        WS_LAP(kWsWaitTicket);
+        TL(p, uni(sm.tq[n % kTq]), 5, lane == 0);
         if (!store_tile(p, sm, n, lane)) return;
+        TL(p, uni(sm.tq[n % kTq]), 6, lane == 0);
+        WS_LAP(kWsStore); WS_COUNT(kWsTiles);
         ++n;
         if (lane == 0) lds_rel(&sm.n_freed, n);
         wake_workgroup();                                      // a data wave may be waiting for ring space or a slot

@@ -8,7 +8,7 @@ os.environ["HVLC_LIB"] = os.path.join(ROOT, "huffman-gpu_amd", "libhvlc_exp.so")
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mib", type=int, default=1024); ap.add_argument("--bpc", type=int, default=3)
+    ap.add_argument("--mib", type=int, default=4096); ap.add_argument("--bpc", type=int, default=0)
     ap.add_argument("--workload", default="H2.2")
     a = ap.parse_args()
     import torch, hvlc
@@ -16,14 +16,14 @@ def main():
     L = hvlc.lib(); L.hvlc_debug_set_timeline.argtypes = [C.c_void_p]
     period = np.fromfile(os.path.join(ROOT, "tests", "golden", "g1_period.bin"), dtype=np.uint8)
     n = a.mib << 20
-    os.environ["HVLC_BLOCKS_PER_CU"] = str(a.bpc)
+    if a.bpc: os.environ["HVLC_BLOCKS_PER_CU"] = str(a.bpc)
     enc = hvlc.Encoder(0, n // 4)
     d_in = enc.gen_symbols(n, SEEDS[a.workload], hvlc.cdf32_from_counts(dist_weights(a.workload, period)))
     hist = enc.histogram(d_in).cpu().numpy().astype(np.uint64)
     cw, cl = hvlc.huffman_table(hist); d_tab = enc.table_to_device(cw, cl)
     out = torch.empty(hvlc.out_capacity_words(n // 4, int(cl.max())), dtype=torch.int32, device="cuda")
     offs = torch.empty(hvlc.num_segments(n // 4), dtype=torch.int64, device="cuda")
-    TILE = 28672                                     # bytes per tile (kTileWords * 4)
+    TILE = 40960                                     # bytes per tile (kTileWords * 4)
     ntiles = n // TILE + (1 if n % TILE else 0)
     for it in range(3):
         tl = torch.zeros(ntiles * 8, dtype=torch.int64, device="cuda")
@@ -44,6 +44,7 @@ def main():
     st("pack -> scout starts polling (us)", (start - pack)[mid])
     st("pack -> resolved", (res - pack)[mid])
     st("resolved -> store begins", (store - res)[mid])
+    st("store begins -> stored", (us(t[:, 6]) - store)[mid])
     st("pack -> store", (store - pack)[mid])
     ng = ntiles // 64
     gsl = slice(ng // 4, 3 * ng // 4)

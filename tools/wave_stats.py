@@ -7,7 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "huffman-gpu_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("HVLC_LIB", os.path.join(ROOT, "huffman-gpu_amd", "libhvlc_exp.so"))
-NAMES = ["encode(+load wait)", "store+prefetch", "arrive", "pack", "wait ticket", "wait drain(end)", "wait slot", "wait ring",
+NAMES = ["encode(+load wait)", "prefetch issue | STORE", "arrive", "zero+pack", "wait ticket | RESOLVE", "-", "wait slot", "wait ring",
          "slow path", "wait tail", "total", "tiles", "nwaits"]
 
 def main():
@@ -27,7 +27,7 @@ def main():
     offs = torch.empty(hvlc.num_segments(n // 4), dtype=torch.int64, device="cuda")
     G = 768
     for it in range(3):
-        ws = torch.zeros(4096 * 8 * 16, dtype=torch.int64, device="cuda")
+        ws = torch.zeros(4096 * 16 * 16, dtype=torch.int64, device="cuda")
         L.hvlc_debug_set_wave_stats(C.c_void_p(ws.data_ptr()))
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -35,7 +35,12 @@ def main():
         e1.record()
         bits, rc = enc.finish(check=False)
     G = enc.launch_info()["grid_blocks"]
-    t = ws.cpu().numpy().reshape(-1, 8, 16)[:G, :7, :].astype(np.float64)      # data waves only
+    allw = ws.cpu().numpy().reshape(-1, 16, 16)[:G].astype(np.float64)
+    NW = 10
+    sw = allw[:, NW + 1, :]                                                      # the store wave
+    print(f"store wave: lifetime (Mclk) {sw[:, 10].mean()/1e6:.3f}  tiles {sw[:, 11].mean():.1f}  storing {100*(sw[:, 1]/sw[:, 10]).mean():.1f} %"
+          f" = {sw[:, 1].sum()/sw[:, 11].sum():.0f} clocks per tile, waiting for a resolved tile {100*(sw[:, 4]/sw[:, 10]).mean():.1f} %")
+    t = allw[:, :NW, :]                                                          # data waves only
     tot = t[:, :, 10]
     print(f"{a.workload} {a.mib} MiB rc {rc} kernel {e0.elapsed_time(e1):.3f} ms  grid {G}  wave lifetime (Mclk) mean {tot.mean()/1e6:.3f} min {tot.min()/1e6:.3f} max {tot.max()/1e6:.3f}"
           f"  tiles per wave {t[:, :, 11].mean():.1f}")
@@ -43,7 +48,7 @@ def main():
         sh = t[:, :, i] / tot
         print(f"  {NAMES[i]:20s} {100*sh.mean():6.2f} %   (p10 {100*np.percentile(sh,10):5.2f}  p90 {100*np.percentile(sh,90):5.2f})   clocks per tile {t[:, :, i].sum() / t[:, :, 11].sum():8.0f}")
     print(f"  clocks per tile total {tot.sum() / t[:, :, 11].sum():8.0f}")
-    bywave = [(t[:, w, 0] / tot[:, w]).mean() for w in range(7)]
+    bywave = [(t[:, w, 0] / tot[:, w]).mean() for w in range(NW)]
     print("  encode share by wave:", " ".join(f"{100*x:.1f}" for x in bywave))
 
 if __name__ == "__main__":
