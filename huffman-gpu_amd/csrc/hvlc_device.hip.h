@@ -444,8 +444,9 @@ constexpr int      kTq      = 16;                          // queue of drawn til
 #ifndef HVLC_TICKETS_AHEAD
 #define HVLC_TICKETS_AHEAD 2
 #endif
-constexpr int      kTixAhead = HVLC_TICKETS_AHEAD;         // tiles the scout draws ahead of the workgroup's slowest data wave
-static_assert(kTq >= kSlots + kTixAhead + 2, "a tile number must stay in the queue until the store wave has stored the tile");
+constexpr int      kTixAhead = HVLC_TICKETS_AHEAD;         // tiles the scout draws ahead of the workgroup's slowest data wave (first guess)
+constexpr int      kTixAheadMax = 3;
+static_assert(kTq >= kSlots + kTixAheadMax + 2, "a tile number must stay in the queue until the store wave has stored the tile");
 #ifndef HVLC_WAVE_RING_WORDS
 #define HVLC_WAVE_RING_WORDS 1752
 #endif
@@ -483,7 +484,7 @@ struct alignas(16) Smem {
     uint32_t  n_freed;                        // store -> data: tiles stored, their ring words zeroed (in order)
     uint32_t  n_exited;                       // waves of the workgroup that have left (the last one reports to the context)
     uint32_t  abort_flag;
-    uint32_t  pad_[1];
+    uint32_t  tix_ahead;                      // data -> scout: tiles to draw ahead of the slowest data wave (from the ring's capacity in parts)
     uint8_t   len_tmp[256];                   // prologue only: the table's lengths, for the layout decision (not zeroed)
 };
 static_assert(kDataWaves <= 16, "Smem::packed[] and the arrival counter hold up to 16 data waves");
@@ -893,8 +894,9 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         uint32_t freed = lds_acq(&sm.n_freed);
         if (n_packed >= (uint32_t)kSlots + freed) {           // the slot's previous tile must have been stored
             WaveWait w;
-            while (n_packed >= (uint32_t)kSlots + (freed = lds_acq(&sm.n_freed)))
+            while (n_packed >= (uint32_t)kSlots + (freed = lds_acq(&sm.n_freed))) {
                 if (!w.step(p, sm, lane)) return;
+            }
         }
         WS_LAP(kWsWaitSlot);
         const uint32_t need = ring_need(T);
@@ -918,6 +920,14 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             if (ln < kDataWaves) sm.wrec[slot][ln].base = incb - b;
             const uint32_t Ttile = (uint32_t)__builtin_amdgcn_readlane((int)incb, kDataWaves - 1);
             if (lane == 0) {
+#ifndef HVLC_FIXED_TICKETS_AHEAD
+                // How far ahead tiles are worth drawing depends on how many parts a ring holds: a drawn tile whose part cannot
+                // be packed (no ring words until older tiles are resolved) is published late, and every tile of its group
+                // waits for it.  Measured (tools/ab.py): 1 tile ahead is best at 3 parts per ring (4 bits per symbol: +6 %
+                // over 2), 3 at 9 parts (1.3 bits per symbol: +3 %), 2 in between.
+                const uint32_t parts = kWaveRing / ring_need(Ttile / (uint32_t)kDataWaves);
+                sm.tix_ahead = parts <= 3u ? 1u : parts >= 8u ? 3u : 2u;
+#endif
                 sm.ts[slot].arrive = 0u;
                 (void)__hip_atomic_fetch_max(&sm.n_bits_pub, n_packed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (cur != p.stall_tile) st_word(&p.bits32()[cur], kValid32 | Ttile);
@@ -934,7 +944,6 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
                 while ((start = ring_place(sm, wave, head, n_packed, lds_acq(&sm.n_freed), need)) == kNoRoom)
                     if (!w.step(p, sm, lane)) return;
             }
-            WS_LAP(kWsWaitRing);
             head = start + need;
             if (lane == 0) *reinterpret_cast<uint2*>(&sm.wrec[slot][wave].start) = make_uint2(start, need);
             zero_words(ring + start, need / 4u, lane);       // (what an older part left there; the store wave only reads)
@@ -1432,7 +1441,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
         // parts that cannot be resolved before the slowest wave has arrived at their tiles, and the tiles of a group,
         // drawn within a microsecond of each other, would be published over many iterations.  The atomic is issued
         // BEHIND this round's polls (in-order return) and its value is used at the top of the next round
-        if (n_final == ~0u && !tix_inflight && n_tix < lds_rlx(&sm.n_bits_pub) + (uint32_t)kTixAhead &&
+        if (n_final == ~0u && !tix_inflight && n_tix < lds_rlx(&sm.n_bits_pub) + lds_rlx(&sm.tix_ahead) &&
             n_tix - n_duty < (uint32_t)(kTq - 1)) {                 // (a tile number stays queued until the duty scan has seen it)
             if (lane == 0)
                 tix_k = __hip_atomic_fetch_add(&p.tickets()[cls * (uint32_t)kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1635,7 +1644,7 @@ k_encode(EncodeParams p)
             for (uint32_t i = (uint32_t)tid; i < nvec; i += (uint32_t)kEncThreads) z[i] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();                                  // the only workgroup-wide barriers (three): LDS initialised
-        if (tid == 0) sm.n_final = ~0u;
+        if (tid == 0) { sm.n_final = ~0u; sm.tix_ahead = (uint32_t)kTixAhead; }
         __syncthreads();
 #ifdef HVLC_PRIO_YOUNG
         if (wave >= 4 && wave < kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_YOUNG);
