@@ -273,6 +273,16 @@ int hvlc_get_launch_info(hvlc_ctx* c, int* grid_blocks, int* blocks_per_cu, int*
 
 int hvlc_last_hip_error(hvlc_ctx* c) { return c ? c->last_hip : 0; }
 
+int hvlc_get_clock_info(hvlc_ctx* c, uint64_t* shader_clocks, uint64_t* realtime_ticks)
+{
+    if (!c || !c->h_status) return HVLC_ERR_ARG;
+    uint64_t v[2];
+    memcpy(v, &c->h_status[kCtlClock], 16);        // (the copy hvlc_finish made of the control block)
+    if (shader_clocks)  *shader_clocks  = v[0];
+    if (realtime_ticks) *realtime_ticks = v[1];
+    return HVLC_OK;
+}
+
 int hvlc_encode(hvlc_ctx* c,
                 const uint32_t* d_in, uint64_t num_words,
                 const uint32_t* d_codewords, const uint32_t* d_codewordlens,

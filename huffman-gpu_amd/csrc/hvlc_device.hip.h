@@ -103,12 +103,14 @@ enum : uint32_t { kFlagTable = 1u, kFlagCapacity = 2u, kFlagTimeout = 4u, kFlagL
 //   [4]      calls completed (incremented by the last wave to leave)  [5]     waves that have left the running launch
 //   [6] [7]  bytes the last call in half 0 / 1 used (what the next launch has to zero)
 //   [8]      status flags of the last hvlc_exclusive_scan              [10..11] uint64 its total
+//   [12..15] lifetime of the last encode's workgroup 0 in shader clocks and in 100 MHz ticks (two uint64)
 // The kernels get ONE base pointer per area and byte offsets instead of eight pointers (fewer live scalar registers in
 // k_encode: with eight, the compiler spilled pointers to VGPR lanes and reloaded them in front of the polls).
 constexpr uint32_t kWsCtlBytes   = 64;
 constexpr uint32_t kCtlResult64  = 1;              // uint64 index
 constexpr uint32_t kCtlCalls     = 4, kCtlExits = 5, kCtlUsed = 6, kCtlScanStatus = 8;
 constexpr uint32_t kCtlScanResult64 = 5;           // uint64 index
+constexpr uint32_t kCtlClock     = 12;             // [12..13] shader clocks, [14..15] 100 MHz ticks of workgroup 0's scout
 constexpr uint32_t kWsOffBits32  = 64 * 32 * 4;    // granule area: tickets [64 x 128 B] | bits32 | recs | group_desc
 
 struct EncodeParams {
@@ -376,6 +378,36 @@ __device__ __forceinline__ void encode16(const uint4& v, const uint2* lut, uint6
         tot = (tot + e3.y) + (e2.y + e1.y + e0.y);
     }
 }
+// The same when the four codewords of every input word fit 32 bits together (the common case: 8 bits per symbol and
+// less): each word's codewords are joined by three 32-bit shift-or instructions (v_lshl_or_b32), only the four word
+// strings of the lane-row by 64-bit shifts -- 2.9 vector instructions per symbol instead of 3.5.  `wmax` returns the
+// longest word string: above 32 the row's `acc` is wrong and the caller encodes the part again with encode16.
+template <bool HASH>
+__device__ __forceinline__ void encode16_w32(const uint4& v, const uint2* lut, uint64_t& acc, uint32_t& tot, uint32_t& wmax)
+{
+    const uint32_t w[4] = { HASH ? hash4(v.x) : v.x, HASH ? hash4(v.y) : v.y, HASH ? hash4(v.z) : v.z, HASH ? hash4(v.w) : v.w };
+    uint32_t cw[4], wl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t h = w[k];
+        const uint2 e3 = lut_at(lut, slot_offset<3>(h));
+        const uint2 e2 = lut_at(lut, slot_offset<2>(h));
+        const uint2 e1 = lut_at(lut, slot_offset<1>(h));
+        const uint2 e0 = lut_at(lut, slot_offset<0>(h));
+        uint32_t c = (e3.x << e2.y) | e2.x;                  // (lengths <= 31: the shifts are defined; v_lshl_or_b32)
+        c = (c << e1.y) | e1.x;
+        c = (c << e0.y) | e0.x;
+        cw[k] = c;
+        wl[k] = (e3.y + e2.y + e1.y) + e0.y;
+    }
+    acc = cw[0];
+    acc = (acc << wl[1]) | cw[1];                             // (a word string of 32 bits: the shift is a 64-bit one)
+    acc = (acc << wl[2]) | cw[2];
+    acc = (acc << wl[3]) | cw[3];
+    tot = (wl[0] + wl[1] + wl[2]) + wl[3];
+    wmax = max(max(wl[0], wl[1]), max(wl[2], wl[3]));
+}
+
 // The hot-path form: the <=64 bits of `acc` (right-aligned, nothing above them) END at part-local bit e (exclusive);
 // always three ORs, no per-lane branches, no left-alignment: with r = e % 32 and W = e / 32 the words W-2, W-1, W
 // take hi >> r, {hi,lo} >> r and lo << (32-r).  Words in front of the string (down to two words in front of st[0])
@@ -385,9 +417,16 @@ __device__ __forceinline__ void put_bits64_end(uint32_t* st, uint32_t e, uint64_
     const uint32_t hi = (uint32_t)(acc >> 32), lo = (uint32_t)acc;
     const uint32_t r = e & 31u;
     uint32_t* w = st + (e >> 5);
+#if defined(HVLC_ABL_PACK_PLAIN)
+    w[-2] = hi >> r; w[-1] = __builtin_amdgcn_alignbit(hi, lo, r); w[0] = __builtin_amdgcn_alignbit(lo, 0u, r);   // (tools/: wrong output)
+    asm volatile("" ::: "memory");
+#elif defined(HVLC_ABL_PACK_ONE)
+    lds_or(w - 1, (hi >> r) ^ __builtin_amdgcn_alignbit(hi, lo, r) ^ __builtin_amdgcn_alignbit(lo, 0u, r));        // (tools/: wrong output)
+#else
     lds_or(w - 2, hi >> r);
     lds_or(w - 1, __builtin_amdgcn_alignbit(hi, lo, r));           // r == 0: lo
     lds_or(w,     __builtin_amdgcn_alignbit(lo, 0u, r));           // r == 0: 0
+#endif
 }
 
 // A lane-row whose 16 codewords exceed 64 bits (lengths up to 31 allow 496): two symbols (<=62 bits)
@@ -819,6 +858,10 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
     uint32_t n_loaded = 0, n_packed = 0, head = 0;           // workgroup-local tile indices: input loaded / part packed; ring: where the next part's words start
     uint32_t n_final = ~0u;
     const uint32_t last_tile = (uint32_t)(p.num_tiles - 1);
+    // 32-bit word strings (encode16_w32): a part in which some word's four codewords exceed 32 bits is encoded again the
+    // general way; a wave that keeps meeting such parts (score: +8 per failure, -1 per success) stops trying for a while
+    constexpr uint32_t kW32Off = 24u;
+    uint32_t w32_score = 0;
     WS_DECL;
 
     // issue the loads of the workgroup's tile number n_loaded if the scout has drawn it
@@ -852,12 +895,29 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         if (full) {
             // (row after row: the four rows advanced together, with the next step's table entries requested ahead --
             // eight to twelve LDS reads in flight instead of four -- took 5 % MORE time: tools/ab.py, round 3)
-            if (permuted) {
+            bool wide = true;
+#ifndef HVLC_NO_W32
+            if (w32_score < kW32Off) {                        // the 32-bit word strings, unless they kept failing lately
+                uint32_t wm[kRows];
+                if (permuted) {
 #pragma unroll
-                for (int r = 0; r < kRows; ++r) encode16<true>(raw[r], sm.lut, acc[r], tot[r]);
-            } else {
+                    for (int r = 0; r < kRows; ++r) encode16_w32<true>(raw[r], sm.lut, acc[r], tot[r], wm[r]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < kRows; ++r) encode16<false>(raw[r], sm.lut, acc[r], tot[r]);
+                    for (int r = 0; r < kRows; ++r) encode16_w32<false>(raw[r], sm.lut, acc[r], tot[r], wm[r]);
+                }
+                wide = __any(max(max(wm[0], wm[1]), max(wm[2], wm[3])) > 32u);
+                w32_score = wide ? w32_score + 8u : (w32_score ? w32_score - 1u : 0u);
+            } else if (++w32_score >= kW32Off + 64u) w32_score = kW32Off - 8u;     // every 64 parts another try
+#endif
+            if (wide) {
+                if (permuted) {
+#pragma unroll
+                    for (int r = 0; r < kRows; ++r) encode16<true>(raw[r], sm.lut, acc[r], tot[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < kRows; ++r) encode16<false>(raw[r], sm.lut, acc[r], tot[r]);
+                }
             }
         } else {
             // the part the input ends in (or an empty one behind it): bit counts only, the slow path packs it (cold code)
@@ -948,7 +1008,13 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             if (lane == 0) *reinterpret_cast<uint2*>(&sm.wrec[slot][wave].start) = make_uint2(start, need);
             zero_words(ring + start, need / 4u, lane);       // (what an older part left there; the store wave only reads)
             uint32_t* const st = ring + start + 1;
+#ifdef HVLC_ABL_NO_PACK
+            if (false) {
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) asm volatile("" :: "v"(acc[r]), "v"(incl[r]));
+#else
             if (!HVLC_DBG(p, kDbgNoPack)) {
+#endif
                 const uint32_t longest = max(max(tot[0], tot[1]), max(tot[2], tot[3]));
                 if (!__any(longest > 64u)) {
 #pragma unroll
@@ -1649,10 +1715,25 @@ k_encode(EncodeParams p)
 #ifdef HVLC_PRIO_YOUNG
         if (wave >= 4 && wave < kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_YOUNG);
 #endif
+#ifdef HVLC_PRIO_TIERS
+        // instruction issue on a SIMD goes to the oldest wave first: the data waves dispatched later lose to their elders
+        if (wave >= 8 && wave < kDataWaves) __builtin_amdgcn_s_setprio(2);
+        else if (wave >= 4 && wave < kDataWaves) __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef HVLC_PRIO_SCOUT
         if (wave == kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_SCOUT);
 #endif
-        if (wave == kDataWaves)          encode_scout_wave(p, sm, lane, first_ticket);
+        if (wave == kDataWaves) {
+            // workgroup 0's scout lives about as long as the launch: its lifetime in shader clocks and in 100 MHz ticks
+            // tells the clock the GPU held (hvlc_get_clock_info)
+            const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+            encode_scout_wave(p, sm, lane, first_ticket);
+            if (blockIdx.x == 0 && lane == 0) {
+                uint64_t* const clk = reinterpret_cast<uint64_t*>(ctl + kCtlClock);
+                clk[0] = __builtin_amdgcn_s_memtime() - c0;
+                clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+            }
+        }
         else if (wave == kDataWaves + 1) {
 #ifndef HVLC_NO_STORE_PRIO
             __builtin_amdgcn_s_setprio(3);       // one short, serial instruction stream that ten data waves wait for

@@ -33,7 +33,7 @@ EXPORTS = [
     "hvlc_finish", "gpu_vlc_encode", "hvlc_segment_bits", "hvlc_exclusive_scan", "hvlc_rebase_offsets",
     "hvlc_rebase_offsets_dev", "hvlc_profile_begin", "hvlc_profile_collect",
     "hvlc_gen_symbols", "hvlc_histogram", "hvlc_build_table", "hvlc_merge_shard", "hvlc_decode", "hvlc_get_launch_info", "hvlc_last_hip_error",
-    "hvlc_status_string", "hvlc_version", "hvlc_test_hook", "hvlc_probe_bandwidth",
+    "hvlc_status_string", "hvlc_version", "hvlc_test_hook", "hvlc_probe_bandwidth", "hvlc_get_clock_info",
 ]
 HOOK_STALL_TILE, HOOK_FORCE_GRID = 1, 2
 
@@ -112,6 +112,7 @@ def lib():
     L.hvlc_histogram.argtypes = [vp, vp, u64, vp, vp]
     L.hvlc_get_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.hvlc_last_hip_error.argtypes = [vp]
+    L.hvlc_get_clock_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.hvlc_test_hook.argtypes = [vp, i32, C.c_int64]
     L.hvlc_probe_bandwidth.argtypes = [vp, vp, u64, vp, u64, u32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.hvlc_status_string.argtypes = [i32]
@@ -189,6 +190,12 @@ class Encoder:
     def test_hook(self, which, value):
         """Test hooks of include/hvlc.h (stall a tile / force the grid size); never used in production."""
         _check(lib().hvlc_test_hook(self._ctx, int(which), int(value)), "hvlc_test_hook")
+
+    def clock_ghz(self):
+        """Shader clock (GHz) the GPU held during the last encode `finish` reported on; 0.0 if none."""
+        c, r = C.c_uint64(0), C.c_uint64(0)
+        lib().hvlc_get_clock_info(self._ctx, C.byref(c), C.byref(r))
+        return c.value / r.value / 10.0 if r.value else 0.0
 
     def launch_info(self):
         g, b, c = C.c_int(0), C.c_int(0), C.c_int(0)

@@ -209,6 +209,11 @@ int hvlc_test_hook(hvlc_ctx* ctx, int which, int64_t value);
  * CUs) and the last HIP error code seen by this context. */
 int hvlc_get_launch_info(hvlc_ctx* ctx, int* grid_blocks, int* blocks_per_cu, int* compute_units);
 int hvlc_last_hip_error(hvlc_ctx* ctx);
+/* The shader clock the GPU held during the last hvlc_encode that hvlc_finish has reported on: workgroup 0 counts its
+ * own lifetime in shader clocks (s_memtime) and in ticks of the constant 100 MHz counter (s_memrealtime); clock in GHz
+ * = shader_clocks / realtime_ticks / 10.  MI355X lowers its clock under load, so a launch's time is set by the clock it
+ * gets as much as by its instruction count.  Zeros before the first finished encode. */
+int hvlc_get_clock_info(hvlc_ctx* ctx, uint64_t* shader_clocks, uint64_t* realtime_ticks);
 const char* hvlc_status_string(int status);
 const char* hvlc_version(void);
 

@@ -124,6 +124,26 @@ def test_adversarial_tables(enc, kind):
         _check(enc, x, cw, cl, f"{kind}/{nwords}")
 
 
+@pytest.mark.parametrize("one_in", [300, 40000])
+def test_word_strings_over_32_bits_inside_short_rows(enc, one_in):
+    """The data waves join the four codewords of an input word with 32-bit operations and encode a part again, the
+    general way, when some word's codewords exceed 32 bits (and stop trying for a while when that keeps happening).
+    A 1-bit symbol with a rare 30-bit one: words of 33 bits inside lane-rows of at most 64 -- in nearly every part
+    (one in 300 symbols) or in a few (one in 40000), over enough tiles for every wave to change its mind both ways."""
+    rng = np.random.default_rng(one_in)
+    cl = np.zeros(256, dtype=np.uint32)
+    cw = np.zeros(256, dtype=np.uint32)
+    cl[7], cw[7] = 1, 0
+    cl[9], cw[9] = 30, (1 << 29) | 0x155555
+    cl[11], cw[11] = 2, 0b10
+    n = 12 << 20
+    x8 = np.full(n, 7, dtype=np.uint8)
+    x8[rng.random(n) < 0.1] = 11
+    x8[rng.choice(n, n // one_in, replace=False)] = 9
+    x8[n // 3: n // 3 + (1 << 20)] = 7                     # a stretch with no long code at all
+    _check(enc, x8.view(np.uint32), cw, cl, f"w32/{one_in}")
+
+
 def test_sparse_bits_cross_tile_carry(enc):
     """Only one symbol in ~2000 emits bits: most tiles hold fewer than 31 bits, so the 31-bit
     carry has to travel through many tiles (and through tiles with no bits at all)."""

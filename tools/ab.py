@@ -25,6 +25,10 @@ def load(path):
     L.hvlc_encode.argtypes = [vp, vp, u64, vp, vp, vp, u64, vp, vp, vp]
     L.hvlc_finish.argtypes = [vp, vp, C.POINTER(u64)]
     L.hvlc_destroy.argtypes = [vp]
+    try:
+        L.hvlc_get_clock_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    except AttributeError:
+        pass
     return L
 
 
@@ -67,6 +71,7 @@ def main():
                                C.c_void_p(out.data_ptr()), out.numel(), C.c_void_p(offs.data_ptr()), None, stream)
             assert rc == 0, rc
         times = {name: [] for name, _ in libs}
+        clocks = {}
         ok = {}
         for (name, L), ctx in zip(libs, ctxs):            # warm-up, and the bit count
             for _ in range(3):
@@ -87,11 +92,16 @@ def main():
                 e1.record()
                 e1.synchronize()
                 times[name].append(e0.elapsed_time(e1) / a.steps)
+                if hasattr(L, "hvlc_get_clock_info"):
+                    bits = C.c_uint64(0); L.hvlc_finish(ctx, stream, C.byref(bits))
+                    cc, rr = C.c_uint64(0), C.c_uint64(0); L.hvlc_get_clock_info(ctx, C.byref(cc), C.byref(rr))
+                    if rr.value: clocks.setdefault(name, []).append(cc.value / rr.value / 10.0)
         ref = statistics.median(times[libs[0][0]])
         for name, _ in libs:
             t = times[name]
             med = statistics.median(t)
-            print(f"{wl:5s} {name:14s} median {med:.4f} ms  min {min(t):.4f}  GB/s {n / med / 1e6:7.1f}  vs {libs[0][0]} {ref / med:.3f}  bits_ok {ok[name]}", flush=True)
+            ck = f"  clock {statistics.median(clocks[name]):.2f} GHz" if name in clocks else ""
+            print(f"{wl:5s} {name:14s} median {med:.4f} ms  min {min(t):.4f}  GB/s {n / med / 1e6:7.1f}  vs {libs[0][0]} {ref / med:.3f}  bits_ok {ok[name]}{ck}", flush=True)
         for (name, L), ctx in zip(libs, ctxs):
             L.hvlc_destroy(ctx)
         del d_in, out, offs
