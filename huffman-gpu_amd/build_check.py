@@ -30,8 +30,18 @@ import subprocess
 import sys
 import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
 HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _llvm_bin():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hvlc_hazard_pass_for_check", os.path.join(HERE, "hazard_pass.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.llvm_bin()
+
+
+LLVM = _llvm_bin()
 
 SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]|\b(vcc)\b|\b(vcc_lo)\b|\b(vcc_hi)\b")
 VMEM_PREFIX = ("global_", "flat_", "scratch_", "buffer_", "tbuffer_")
@@ -117,8 +127,9 @@ def scan(disassembly, min_ws):
                 last_write[r] = (clock, ins)
         elif mnem.startswith("s_") and not mnem.startswith(SMEM_PREFIX):
             parts = [p.strip() for p in ops.split(",")]     # a SALU write replaces the VALU one (interlocked in hardware)
-            if parts and mnem not in ("s_nop", "s_waitcnt", "s_sleep", "s_branch", "s_barrier") and not mnem.startswith("s_cbranch") \
-               and not mnem.startswith("s_cmp") and not mnem.startswith("s_bitcmp"):
+            # (not s_cmov*: it writes nothing when SCC = 0, the VALU value may still be the one that is read)
+            if parts and mnem not in ("s_nop", "s_waitcnt", "s_sleep", "s_branch", "s_barrier", "s_cmov_b32", "s_cmov_b64", "s_cmovk_i32") \
+               and not mnem.startswith("s_cbranch") and not mnem.startswith("s_cmp") and not mnem.startswith("s_bitcmp"):
                 for r in sregs(parts[0]):
                     last_write.pop(r, None)
         clock += 1

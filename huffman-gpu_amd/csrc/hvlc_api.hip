@@ -10,6 +10,9 @@
 // launch path once the workspace is large enough (graph-capture friendly), and
 // nothing falls back to a CPU implementation: without a GPU every compute entry
 // point fails with HVLC_ERR_NO_DEVICE / HVLC_ERR_HIP.
+#ifndef HVLC_HAZARD_PASS
+#error "libhvlc.so must be built by huffman-gpu_amd/hazard_pass.py (make -C huffman-gpu_amd, or hvlc.build()): k_encode's waves wake each other, and an s_wakeup ends the s_nop wait states of the waves it reaches -- a plain hipcc build reads stale registers as addresses (DESIGN.md 4.4)"
+#endif
 #include "../../include/hvlc.h"
 #include "hvlc_device.hip.h"
 
@@ -337,10 +340,10 @@ int hvlc_encode(hvlc_ctx* c,
 #endif
 
     c->last_grid = (int)grid;
-    c->last_op = 1;
     const bool prof = c->ev && c->ev_used < c->ev_cap;
     if (prof) HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used], s));
     HVLC_HIP(c, launch(k_encode, dim3((unsigned)grid), dim3(kEncThreads), sizeof(Smem), s, p));
+    c->last_op = 1;                                           // (only a launched encode is what hvlc_finish reports on)
     if (prof) { HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used + 1], s)); c->ev_used++; }
     return HVLC_OK;
 }
@@ -480,6 +483,7 @@ int hvlc_exclusive_scan(hvlc_ctx* c, const uint32_t* d_counts, uint64_t n,
     const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
     if (tiles == 0) {
         if (d_total) HVLC_HIP(c, hipMemsetAsync(d_total, 0, 8, s));
+        c->last_op = 0;                                       // hvlc_finish: an empty call, HVLC_OK and 0
         return HVLC_OK;
     }
     int rc = ensure_scan_workspace(c, tiles);
@@ -495,12 +499,12 @@ int hvlc_exclusive_scan(hvlc_ctx* c, const uint32_t* d_counts, uint64_t n,
     // granules zeroed and the status word reset by a kernel: the status words are only ever touched with atomic RMWs
     rc = zero_area(c, c->scan_ws, l.scan_bytes, ws_ctl(c) + kCtlScanStatus, (uint64_t*)c->ws + kCtlScanResult64, s);
     if (rc != HVLC_OK) return rc;
-    c->last_op = 2;
     if (!c->scan_blocks_per_cu) c->scan_blocks_per_cu = pick_blocks_per_cu(c, k_exclusive_scan, kThreads, 0, 4);
     const int scan_bpc = c->scan_blocks_per_cu;
     uint64_t grid = (uint64_t)c->cus * (uint64_t)scan_bpc;
     if (grid > tiles) grid = tiles;
     HVLC_HIP(c, launch(k_exclusive_scan, dim3((unsigned)grid), dim3(kThreads), 0, s, d_counts, n, d_offsets, d_total, p));
+    c->last_op = 2;                                           // (only a launched scan is what hvlc_finish reports on)
     return HVLC_OK;
 }
 

@@ -1969,7 +1969,9 @@ __global__ void __launch_bounds__(kThreads) k_merge_shard(const uint32_t* __rest
     for (uint64_t t = tid0; t < nscalar; t += nthr) {
         const uint64_t k = t < head ? t : tail0 + (t - head);
         const uint32_t v = merge_word(src, k, s, nd, ns, nbits);
-        if (k == 0 || k == nd - 1) { if (v) atomicOr(&dst[w0 + k], v); }
+        // (system scope: the word may be peer memory that another GPU ORs its own seam bits into -- an agent-scope
+        // atomic could be resolved in the issuing GPU's L2 and lose the other's bits when the line is written back)
+        if (k == 0 || k == nd - 1) { if (v) (void)__hip_atomic_fetch_or(&dst[w0 + k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         else dst[w0 + k] = v;
     }
 }

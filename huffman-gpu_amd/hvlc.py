@@ -50,23 +50,34 @@ def build(force=False, verbose=False):
         newest = max(os.path.getmtime(p) for p in DEPS)
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
-    staged = LIB_PATH + ".new"
-    # Two steps of our own around hipcc (no plain `hipcc -shared`): an s_wakeup from another wave of a workgroup ends an
-    # `s_nop N` in progress, so in a kernel whose waves wake each other the compiler's wait states are not real (a
-    # spilled pointer reloaded 5 wait states in front of a load was read stale on MI355X).  hazard_pass.py splits those
-    # s_nop into single ones and puts an interlocked SALU copy in front of every memory instruction whose address
-    # register a VALU instruction wrote shortly before; build_check.py verifies the finished library.
+    # Two steps of our own around hipcc (no plain `hipcc -shared`: hvlc_api.hip refuses to compile without the pass's
+    # -DHVLC_HAZARD_PASS): an s_wakeup from another wave of a workgroup ends an `s_nop N` in progress, so in a kernel whose
+    # waves wake each other the compiler's wait states are not real (a spilled pointer reloaded 5 wait states in front of a
+    # load was read stale on MI355X).  hazard_pass.py splits those s_nop into single ones and puts an interlocked SALU copy
+    # in front of every memory instruction whose address register a VALU instruction wrote shortly before;
+    # build_check.py verifies the finished library.
+    # Several ranks (torchrun, the gloo tests) may get here at once with a stale library: one builds, under a file lock,
+    # into a staged file of its own; the others wait for the lock and find the library fresh.
+    import fcntl
     hazard_pass, build_check = _load_sibling("hazard_pass"), _load_sibling("build_check")
-    report = hazard_pass.build_library(staged, SRC[0], verbose=verbose)
-    if verbose:
-        print("hazard pass:", {k: v for k, v in report.items() if v} or "nothing to insert")
-    found = build_check.check(staged)
-    if found:
-        os.remove(staged)
-        raise RuntimeError("libhvlc.so refused by build_check.py:\n" +
-                           "\n".join((f"  {k}: `{i}`: {w}" if r == "-" else f"  {k}: `{i}` reads {r} {d} wait states after `{w}`")
-                                     for k, i, r, d, w in found))
-    os.replace(staged, LIB_PATH)
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in DEPS):
+            return LIB_PATH                                   # (another process built it while this one waited)
+        staged = "%s.%d.new" % (LIB_PATH, os.getpid())
+        try:
+            report = hazard_pass.build_library(staged, SRC[0], verbose=verbose)
+            if verbose:
+                print("hazard pass:", {k: v for k, v in report.items() if v} or "nothing to insert")
+            found = build_check.check(staged)
+            if found:
+                raise RuntimeError("libhvlc.so refused by build_check.py:\n" +
+                                   "\n".join((f"  {k}: `{i}`: {w}" if r == "-" else f"  {k}: `{i}` reads {r} {d} wait states after `{w}`")
+                                             for k, i, r, d, w in found))
+            os.replace(staged, LIB_PATH)
+        finally:
+            if os.path.exists(staged):
+                os.remove(staged)
     return LIB_PATH
 
 

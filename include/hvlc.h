@@ -85,6 +85,9 @@ uint64_t hvlc_num_segments(uint64_t num_words);
  * memset) once the context is large enough: capturable into a HIP graph.
  * Errors found on the device (table, capacity, timeout) are reported by
  * hvlc_finish.  Not re-entrant per context (one encode in flight per ctx).
+ * Device requirement: an input of more than one 40 KiB tile per resident
+ * workgroup needs at least 64 workgroups resident at once (two per compute
+ * unit: 32 CUs) -- fewer, e.g. a small compute partition, is HVLC_ERR_ARG.
  */
 int hvlc_encode(hvlc_ctx* ctx,
                 const uint32_t* d_in, uint64_t num_words,
@@ -93,10 +96,12 @@ int hvlc_encode(hvlc_ctx* ctx,
                 uint64_t* d_out_offsets, uint64_t* d_total_bits,
                 void* stream);
 
-/* Wait for the last hvlc_encode (or hvlc_exclusive_scan) of this context on `stream`,
+/* Wait for the last hvlc_encode (or hvlc_exclusive_scan) of this context that was LAUNCHED on `stream`,
  * return its total (bits / sum) and its device-side status
  * (HVLC_OK / _TABLE / _CAPACITY / _TIMEOUT).  After a _TIMEOUT the outputs of that call are
- * incomplete and must not be used. */
+ * incomplete and must not be used.  An empty call (num_words == 0, n == 0) counts: it reports
+ * HVLC_OK and a total of 0, never the result of an earlier call; a call that failed before its
+ * launch (an error return) leaves what hvlc_finish reports on unchanged. */
 int hvlc_finish(hvlc_ctx* ctx, void* stream, uint64_t* total_bits);
 
 /*
@@ -182,7 +187,9 @@ int hvlc_build_table(const uint64_t* hist, uint32_t max_len, uint32_t* codewords
  * GPU) to bit position dst_bit_offset of d_dst_bits: what pack2 (pack_kernels.cu:19-52) does for 256-word
  * blocks, for whole shards.  Interior destination words are overwritten; the first and the last one, which the
  * neighbouring shards share, are merged with an atomic OR and must be ZERO before the first merge that touches
- * them (zero-fill the seam words or all of d_dst_bits once).  Shards may be merged in any order, concurrently.
+ * them (zero-fill the seam words or all of d_dst_bits once).  Shards may be merged in any order, concurrently --
+ * also by several GPUs into one destination: d_dst_bits may be peer-mapped memory of another GPU (the two seam
+ * words are merged with SYSTEM-scope atomics, so that a seam word OR-ed from two devices is resolved at its home).
  * Merging every shard at its base (hvlc_rebase_offsets[_dev]'s base) into a zeroed buffer of
  * floor(total/32)+1 words reproduces cpu_vlc_encode's stream of the whole input. */
 int hvlc_merge_shard(hvlc_ctx* ctx, const uint32_t* d_src_bits, uint64_t nbits, uint32_t* d_dst_bits,

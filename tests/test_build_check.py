@@ -123,7 +123,7 @@ def test_pass_is_complete_and_idempotent_on_the_real_device_code(tmp_path):
         pytest.skip("no hipcc")
     src = os.path.join(PKG, "csrc", "hvlc_api.hip")
     asm = str(tmp_path / "dev.s")
-    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-command-line-argument", "-S",
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-command-line-argument", "-DHVLC_HAZARD_PASS", "-S",
                     "--cuda-device-only", "-o", asm, src], check=True, cwd=os.path.dirname(src))
     text = open(asm).read()
     nops1, nops2 = {}, {}
@@ -214,3 +214,58 @@ def test_pass_splits_multi_state_nops_only_where_waves_wake_each_other():
     assert ins.count("s_nop 1") == 1 and ins.count("s_nop 3") == 1 and ins.count("s_nop 0") == 1
     dis = "0 <k>:\n\ts_nop 1\n\ts_wakeup\n\ts_nop 0\n10 <quiet>:\n\ts_nop 3\n"
     assert bc.multi_state_nops(dis) == [("k", "s_nop 1")]
+
+
+# ---- round 3: the gate is the only door and the conditional SALU forms -----------------------
+import shutil
+import subprocess
+
+
+def test_a_conditional_move_does_not_count_as_the_salu_write():
+    """s_cmov writes nothing when SCC = 0: the VALU-written value may still be the one the load reads."""
+    seq = ("0 <k>:\n\tv_readlane_b32 s4, v1, 0\n\tv_readlane_b32 s5, v1, 1\n\ts_cmov_b64 s[4:5], s[8:9]\n"
+           "\tglobal_load_dword v2, v0, s[4:5]\n")
+    assert [f[2] for f in bc.scan(seq, 12)] == ["s4", "s5"]
+    assert bc.scan(seq.replace("s_cmov_b64", "s_mov_b64"), 12) == []
+    hp = _hazard_pass()
+    asm = ("\tv_readlane_b32 s4, v1, 0\n\tv_readlane_b32 s5, v1, 1\n\ts_cmov_b64 s[4:5], s[8:9]\n"
+           "\tglobal_load_dword v2, v0, s[4:5]\n\ts_endpgm\n").splitlines(keepends=True)
+    out, n, _ = hp.patch_function(asm, hp.WINDOW)
+    assert n == 2 and sum("hazard pass" in l for l in out) == 2
+    out2, n2, _ = hp.patch_function([l.replace("s_cmov_b64", "s_mov_b64") for l in asm], hp.WINDOW)
+    assert n2 == 0
+
+
+def test_a_scalar_store_operand_is_not_a_destination():
+    hp = _hazard_pass()
+    asm = ("\tv_readlane_b32 s4, v1, 0\n\ts_store_dword s4, s[8:9], 0x0\n\tbuffer_load_dword v2, off, s[12:15], s4\n\ts_endpgm\n"
+           ).splitlines(keepends=True)
+    _, n, _ = hp.patch_function(asm, hp.WINDOW)
+    assert n == 1                      # s4 is still "VALU-written" at the load: the store only read it
+
+
+def _hazard_pass():
+    spec = importlib.util.spec_from_file_location("hvlc_hazard_pass_t", os.path.join(PKG, "hazard_pass.py"))
+    hp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hp)
+    return hp
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+def test_a_bare_hipcc_build_of_the_library_is_refused():
+    """libhvlc.so's source compiles only through hazard_pass.py (which defines HVLC_HAZARD_PASS): the binary a plain
+    `hipcc -shared csrc/hvlc_api.hip` would give is the one that faulted in round 2."""
+    src = os.path.join(PKG, "csrc", "hvlc_api.hip")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "--cuda-host-only", "-fsyntax-only", src], capture_output=True, text=True)
+    assert r.returncode != 0 and "hazard_pass.py" in r.stderr
+    ok = subprocess.run(["hipcc", "--offload-arch=gfx950", "--cuda-host-only", "-fsyntax-only", "-DHVLC_HAZARD_PASS", src],
+                        capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+
+
+def test_the_makefiles_build_the_library_through_the_pass_and_the_gate():
+    """The C hosts' Makefile depends on ../libhvlc.so, whose only rule runs hazard_pass.py and build_check.py."""
+    r = subprocess.run(["make", "-n", "-B", "-C", PKG, "libhvlc.so"], capture_output=True, text=True)
+    assert r.returncode == 0 and "hazard_pass.py" in r.stdout and "build_check.py" in r.stdout and "hipcc -shared" not in r.stdout
+    host = open(os.path.join(PKG, "host", "Makefile")).read()
+    assert "$(HERE)../libhvlc.so:" in host and "$(MAKE) -C $(HERE).. libhvlc.so" in host
