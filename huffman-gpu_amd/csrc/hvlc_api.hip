@@ -655,12 +655,19 @@ int hvlc_probe_bandwidth(hvlc_ctx* c, const void* d_in, uint64_t n_bytes, void* 
                          uint32_t out_words_per_4k, int store_shape, int iters, float* ms_best, float* ms_median)
 {
     if (!c || !d_in || !ms_best || n_bytes < 4096 || ((uintptr_t)d_in & 15u) || iters < 1 || iters > 64 ||
-        store_shape < 0 || store_shape > 4)
+        store_shape < 0 || store_shape > 7)
         return HVLC_ERR_ARG;
     const uint64_t tiles = n_bytes / 4096;
-    if (store_shape) {
-        if (!d_out || ((uintptr_t)d_out & 15u) || out_words_per_4k == 0 || ((store_shape == 2 || store_shape == 4) && (out_words_per_4k & 3u)) ||
-            tiles * (uint64_t)out_words_per_4k * 4u > out_bytes)
+    const bool vec4 = store_shape == 2 || store_shape >= 4;
+    const uint32_t burst = store_shape == 5 ? 10u : store_shape == 6 ? 32u : 1u;
+    if (store_shape == 7) {
+        if (!d_out || ((uintptr_t)d_out & 15u) || tiles * 4096u > out_bytes) return HVLC_ERR_ARG;
+    } else if (store_shape) {
+        // (a burst region is per wave: the output of ceil(steps / burst) bursts of every wave of the grid)
+        const uint64_t waves = (uint64_t)c->cus * 8u * 4u;
+        const uint64_t need = burst == 1u ? tiles * (uint64_t)out_words_per_4k * 4u
+                                          : ((tiles / waves + burst) / burst + 1u) * waves * (uint64_t)out_words_per_4k * burst * 4u;
+        if (!d_out || ((uintptr_t)d_out & 15u) || out_words_per_4k == 0 || (vec4 && (out_words_per_4k & 3u)) || need > out_bytes)
             return HVLC_ERR_ARG;
     }
     HVLC_HIP(c, hipSetDevice(c->device));
@@ -668,17 +675,23 @@ int hvlc_probe_bandwidth(hvlc_ctx* c, const void* d_in, uint64_t n_bytes, void* 
     HVLC_HIP(c, hipEventCreate(&e0));
     HVLC_HIP(c, hipEventCreate(&e1));
     const dim3 grid((unsigned)c->cus * 8u), block(kThreads);      // 32 waves per CU, two 4 KiB steps in flight each
-    uint32_t* sink = ws_ctl(c) + 15;                              // a workspace word nobody reads
+    uint32_t* sink = ws_ctl(c) + 9;                               // a workspace word nobody reads
     std::vector<float> ms((size_t)iters);
     int rc = HVLC_OK;
     for (int i = 0; i < iters && rc == HVLC_OK; ++i) {
         hipError_t e = hipEventRecord(e0, nullptr);
         if (e == hipSuccess) {
-            if (store_shape == 0)      e = launch(k_probe_rw<0>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
-            else if (store_shape == 1) e = launch(k_probe_rw<1>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
-            else if (store_shape == 2) e = launch(k_probe_rw<2>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
-            else if (store_shape == 3) e = launch(k_probe_rw<3>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
-            else                       e = launch(k_probe_rw<4>, grid, block, 0, nullptr, (const uint4*)d_in, tiles, (uint32_t*)d_out, out_words_per_4k, sink);
+            const uint4* in = (const uint4*)d_in; uint32_t* out = (uint32_t*)d_out;
+            switch (store_shape) {
+                case 0:  e = launch(k_probe_rw<0>, grid, block, 0, nullptr, in, tiles, out, out_words_per_4k, burst, sink); break;
+                case 1:  e = launch(k_probe_rw<1>, grid, block, 0, nullptr, in, tiles, out, out_words_per_4k, burst, sink); break;
+                case 2:  e = launch(k_probe_rw<2>, grid, block, 0, nullptr, in, tiles, out, out_words_per_4k, burst, sink); break;
+                case 3:  e = launch(k_probe_rw<3>, grid, block, 0, nullptr, in, tiles, out, out_words_per_4k, burst, sink); break;
+                case 4:  e = launch(k_probe_rw<4>, grid, block, 0, nullptr, in, tiles, out, out_words_per_4k, burst, sink); break;
+                case 5: case 6:
+                         e = launch(k_probe_rw<5>, grid, block, 0, nullptr, in, tiles, out, out_words_per_4k, burst, sink); break;
+                default: e = launch(k_probe_copy, dim3((unsigned)c->cus * 4u), block, 0, nullptr, in, (uint4*)d_out, tiles * 256u); break;
+            }
         }
         if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
         if (e == hipSuccess) e = hipEventSynchronize(e1);

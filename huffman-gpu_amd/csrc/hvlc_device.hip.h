@@ -2186,12 +2186,15 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
 // encoder's ACCESS PATTERN -- every wave reads 4 KiB (4 x dwordx4 nt per lane) per step, two steps in flight --
 // and, for the mix, writes `wpt` words per 4 KiB read to a contiguous stream (the stream words of the step before,
 // so that the stores never wait for the loads just issued).
-//   STORE 0: read only   1: one dword per lane per store (the encoder's store shape)   2: dwordx4 per lane
+//   STORE 0: read only   1: one dword per lane per store instruction   2: dwordx4 per lane
 //         3, 4: the same two with non-temporal stores
+//         5, 6: dwordx4 non-temporal stores in BURSTS: a wave writes the output of `burst` steps (10: a tile's worth, what
+//               the encoder's store wave does; 32) as one contiguous stretch every `burst`-th step
+// k_probe_copy: a plain 1:1 copy (dwordx4 non-temporal loads and stores), the known-good reference of a read/write mix.
 // ---------------------------------------------------------------------------------------------
 template <int STORE>
 __global__ void __launch_bounds__(kThreads) k_probe_rw(const uint4* __restrict__ in, uint64_t tiles4k, uint32_t* __restrict__ out,
-                                                       uint32_t wpt, uint32_t* sink)
+                                                       uint32_t wpt, uint32_t burst, uint32_t* sink)
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
@@ -2199,20 +2202,21 @@ __global__ void __launch_bounds__(kThreads) k_probe_rw(const uint4* __restrict__
     const u32x4* src = (const u32x4*)in;
     uint32_t acc = 0, prev = 0;
     u32x4 a, b, c, d;
-    uint64_t t = w0;
+    uint64_t t = w0, it = 0;
+    auto store = [&](uint32_t* dst, uint32_t n) {
+        if (STORE == 1)      { for (uint32_t k = lane; k < n; k += 64) dst[k] = prev; }
+        else if (STORE == 2) { for (uint32_t k = lane * 4; k + 3 < n; k += 256) *(u32x4*)(dst + k) = (u32x4){prev, prev, prev, prev}; }
+        else if (STORE == 3) { for (uint32_t k = lane; k < n; k += 64) __builtin_nontemporal_store(prev, dst + k); }
+        else                 { for (uint32_t k = lane * 4; k + 3 < n; k += 256) __builtin_nontemporal_store((u32x4){prev, prev, prev, prev}, (u32x4*)(dst + k)); }
+    };
     if (t < tiles4k) {
         const u32x4* q = src + t * 256u + lane;
         a = __builtin_nontemporal_load(q); b = __builtin_nontemporal_load(q + 64); c = __builtin_nontemporal_load(q + 128); d = __builtin_nontemporal_load(q + 192);
     }
-    for (; t < tiles4k; t += nw) {
+    for (; t < tiles4k; t += nw, ++it) {
         // the stores of the PREVIOUS step first, then the next step's loads, then the wait for this step's data
-        if (STORE && t != w0) {
-            uint32_t* dst = out + (t - nw) * (uint64_t)wpt;
-            if (STORE == 1)      { for (uint32_t k = lane; k < wpt; k += 64) dst[k] = prev; }
-            else if (STORE == 2) { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) *(u32x4*)(dst + k) = (u32x4){prev, prev, prev, prev}; }
-            else if (STORE == 3) { for (uint32_t k = lane; k < wpt; k += 64) __builtin_nontemporal_store(prev, dst + k); }
-            else                 { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) __builtin_nontemporal_store((u32x4){prev, prev, prev, prev}, (u32x4*)(dst + k)); }
-        }
+        if (STORE && STORE < 5 && t != w0) store(out + (t - nw) * (uint64_t)wpt, wpt);
+        if (STORE >= 5 && it && (it % burst) == 0u) store(out + ((it / burst - 1u) * nw + w0) * (uint64_t)(wpt * burst), wpt * burst);
         u32x4 na = a, nb = b, nc = c, nd = d;
         if (t + nw < tiles4k) {
             const u32x4* q = src + (t + nw) * 256u + lane;
@@ -2222,15 +2226,23 @@ __global__ void __launch_bounds__(kThreads) k_probe_rw(const uint4* __restrict__
         acc += prev;
         a = na; b = nb; c = nc; d = nd;
     }
-    if (STORE && tiles4k > w0) {                       // the last step's words
+    if (STORE && STORE < 5 && tiles4k > w0) {          // the last step's words
         const uint64_t tl = w0 + ((tiles4k - 1 - w0) / nw) * nw;
-        uint32_t* dst = out + tl * (uint64_t)wpt;
-        if (STORE == 1)      { for (uint32_t k = lane; k < wpt; k += 64) dst[k] = prev; }
-        else if (STORE == 2) { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) *(u32x4*)(dst + k) = (u32x4){prev, prev, prev, prev}; }
-        else if (STORE == 3) { for (uint32_t k = lane; k < wpt; k += 64) __builtin_nontemporal_store(prev, dst + k); }
-        else                 { for (uint32_t k = lane * 4; k + 3 < wpt; k += 256) __builtin_nontemporal_store((u32x4){prev, prev, prev, prev}, (u32x4*)(dst + k)); }
+        store(out + tl * (uint64_t)wpt, wpt);
+    }
+    if (STORE >= 5 && it) {                            // what is left of the last burst
+        const uint64_t done = (it - 1u) / burst * burst, left = it - done;
+        store(out + (((it - 1u) / burst) * nw + w0) * (uint64_t)(wpt * burst), (uint32_t)left * wpt);
     }
     if (acc == 0x12345678u) *sink = acc;
+}
+
+__global__ void __launch_bounds__(kThreads) k_probe_copy(const uint4* __restrict__ in, uint4* __restrict__ out, uint64_t nvec)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t stride = (uint64_t)gridDim.x * kThreads;
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load((const u32x4*)in + i), (u32x4*)out + i);
 }
 
 // ---------------------------------------------------------------------------------------------

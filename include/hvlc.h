@@ -155,8 +155,11 @@ int hvlc_profile_collect(hvlc_ctx* ctx, float* ms, int* count);
  * n_bytes from d_in (4 x dwordx4 non-temporal loads per lane per 4 KiB, the encoder's load shape) and, for
  * store_shape != 0, write out_words_per_4k words per 4 KiB read to a contiguous stream in d_out (the encoder's
  * traffic mix: 1024 * bits_per_symbol / 32 words per 4 KiB).  store_shape 0 = read only, 1 = one dword per lane
- * per store instruction (the encoder's store shape), 2 = dwordx4 per lane (out_words_per_4k % 4 == 0),
- * 3 / 4 = the same two with non-temporal stores.
+ * per store instruction, 2 = dwordx4 per lane (out_words_per_4k % 4 == 0), 3 / 4 = the same two with non-temporal
+ * stores, 5 / 6 = dwordx4 non-temporal stores in bursts: a wave writes the output of 10 steps (a tile's worth: the
+ * shape of the encoder's store wave) / of 32 steps as one contiguous stretch (d_out must hold a region per wave and
+ * burst: about twice the stream), 7 = a plain 1:1 copy of the input (out_bytes >= n_bytes; out_words_per_4k
+ * ignored): the known-good reference of a read/write mix.  The ceiling of a workload's mix is the BEST of the shapes.
  * Synchronous on the default stream; runs `iters` launches and returns the best and the median duration in ms. */
 int hvlc_probe_bandwidth(hvlc_ctx* ctx, const void* d_in, uint64_t n_bytes, void* d_out, uint64_t out_bytes,
                          uint32_t out_words_per_4k, int store_shape, int iters, float* ms_best, float* ms_median);

@@ -539,12 +539,25 @@ def test_probe_bandwidth_shapes_and_argument_checks(enc):
         best, med = enc.probe_bandwidth(d_in, out, wpt, shape)
         assert 0 < best <= med
         assert bool((out[words:] == -1).all()) and not bool((out[:words] == -1).all())
+    # bursts (the store wave's shape: a wave writes ten or 32 steps' output as one stretch) and the plain 1:1 copy
+    big = torch.full((160 << 20,), -1, dtype=torch.int32, device="cuda")        # (a region per wave and burst: 604 MB at 32 steps)
+    for shape in (5, 6):
+        best, med = enc.probe_bandwidth(d_in, big, wpt, shape)
+        assert 0 < best <= med and int((big != -1).sum()) == words       # every step's words, each exactly once
+        big.fill_(-1)
+    cp = torch.full((n // 4 + 64,), -1, dtype=torch.int32, device="cuda")
+    best, med = enc.probe_bandwidth(d_in, cp, 0, 7)
+    assert 0 < best <= med and bool((cp[: n // 4] == d_in).all()) and bool((cp[n // 4:] == -1).all())
     with pytest.raises(RuntimeError):
         enc.probe_bandwidth(d_in, torch.empty(16, dtype=torch.int32, device="cuda"), wpt, 1)      # output too small
     with pytest.raises(RuntimeError):
         enc.probe_bandwidth(d_in, torch.empty(words, dtype=torch.int32, device="cuda"), 290, 2)   # dwordx4 stores: multiple of 4
     with pytest.raises(RuntimeError):
-        enc.probe_bandwidth(d_in, torch.empty(words, dtype=torch.int32, device="cuda"), wpt, 5)   # no such shape
+        enc.probe_bandwidth(d_in, torch.empty(words, dtype=torch.int32, device="cuda"), wpt, 5)   # bursts: a region per wave
+    with pytest.raises(RuntimeError):
+        enc.probe_bandwidth(d_in, torch.empty(words, dtype=torch.int32, device="cuda"), wpt, 7)   # copy: as large as the input
+    with pytest.raises(RuntimeError):
+        enc.probe_bandwidth(d_in, torch.empty(words, dtype=torch.int32, device="cuda"), wpt, 8)   # no such shape
 
 
 @pytest.mark.parametrize("world", [2, 5])
@@ -848,3 +861,26 @@ def test_encode_is_graph_capturable(golden):
         assert np.array_equal(out[: rbits // 32 + 1].cpu().numpy().view(np.uint32), ref)
         assert np.array_equal(offs.cpu().numpy().view(np.uint64), roffs)
     e.close()
+
+
+@pytest.mark.gpu
+def test_bench_runs_its_multi_rank_branch_on_one_gpu():
+    """bench.py's N > 1 code end to end -- torch.distributed.run, two ranks, the all-reduced histogram, hvlc.stitch in the
+    step, the whole-shard comparison, the per-rank roofline -- rehearsed on this one GPU (HVLC_BENCH_REHEARSAL=1: both
+    ranks on cuda:0, collectives over gloo).  The driver's 8-GPU run executes the same branch over RCCL."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HVLC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--size-mib", "64", "--steps", "3",
+                        "--warmup", "1", "--no-probe"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rehearsal"] is True and line["bit_exact"] is True
+    assert line["config"]["parallelism"] == "shard2" and line["scaling"] == "weak"
+    assert line["checked_bytes"] > 2 * (64 << 20) // 8                   # both shards whole: about 2 x 64 MiB x 0.278
+    assert len(line["roofline"]["ranks"]["kernel_ms"]) == 2 and all(v > 0 for v in line["roofline"]["ranks"]["kernel_ms"])

@@ -42,7 +42,7 @@ def _worker(rank, world, port, shard_bytes, q):
     shard = O.gen_symbols(shard_bytes, 0x5EED0005, cdf, first_draw=hvlc.shard_first_draw(rank, shard_bytes))
     hist = torch.from_numpy(O.histogram(shard).astype(np.int64))
     dist.all_reduce(hist)                                        # table of the WHOLE job's histogram, as bench.py does
-    cw, cl = hvlc.huffman_table(hist.numpy().astype(np.uint64))
+    cw, cl = hvlc.build_table(hist.numpy().astype(np.uint64))     # libhvlc's own builder: what bench.py and hvlc_mgpu.c call
     x = shard.view(np.uint32)
     words, bits = O.encode(x, cw, cl)                            # stands in for hvlc_encode on this rank's GPU
     _, offs, _ = O.segment_offsets(x, cl)
@@ -83,8 +83,10 @@ def test_multi_rank_job_matches_single_stream(golden, world):
     whole = O.gen_symbols(world * shard_bytes, 0x5EED0005, cdf)            # ONE generation from draw 0
     cw, cl = np.array(res[0][5], dtype=np.uint32), np.array(res[0][6], dtype=np.uint32)
     assert all(r[5] == res[0][5] and r[6] == res[0][6] for r in res)       # same table on every rank
-    cw1, cl1 = hvlc.huffman_table(O.histogram(whole))
+    cw1, cl1 = hvlc.build_table(O.histogram(whole))
     assert np.array_equal(cw, cw1) and np.array_equal(cl, cl1)             # ... and it is the whole job's table
+    cw2, cl2 = hvlc.huffman_table(O.histogram(whole))                      # the Python twin (tools/, older tests) agrees
+    assert np.array_equal(cw, cw2) and np.array_equal(cl, cl2)
     x = whole.view(np.uint32)
     ref_words, ref_bits = O.encode(x, cw, cl)
     _, ref_offs, _ = O.segment_offsets(x, cl)
@@ -120,3 +122,14 @@ def test_shard_bounds_properties():
             sizes = [(a1 - a0 + 255) // 256 for a0, a1 in cuts]
             assert max(sizes) - min(sizes) <= 1
     assert hvlc.stitch_base([5, 7, 11], 0) == 0 and hvlc.stitch_base([5, 7, 11], 2) == 12
+
+
+@pytest.mark.parametrize("name", ["H2.2", "H4.0", "H1.0"])
+def test_the_two_table_builders_agree_on_the_job_histograms(golden, name):
+    """bench.py and hvlc_mgpu.c build the job's table with hvlc_build_table (C, in libhvlc.so); hvlc.huffman_table is its
+    Python twin.  On the histograms of the three benchmark distributions (a few MiB of each) they give the same table."""
+    from util import dist_weights, SEEDS
+    cdf = hvlc.cdf32_from_counts(dist_weights(name, golden["period"]))
+    hist = O.histogram(O.gen_symbols(3 << 20, SEEDS[name], cdf))
+    a, b = hvlc.build_table(hist), hvlc.huffman_table(hist)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
