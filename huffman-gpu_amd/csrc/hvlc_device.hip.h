@@ -179,7 +179,11 @@ struct WaveStats {
 #else
 #define TL(p, tile, k, cond)
 #define TLV(p, tile, k, v, cond)
+#ifdef HVLC_ABL_MASK
+#define HVLC_DBG(p, bit) (((HVLC_ABL_MASK) & (bit)) != 0u)      // (tools/: a compile-time ablation without the instrumentation)
+#else
 #define HVLC_DBG(p, bit) false
+#endif
 #define WS_DECL
 #define WS_LAP(i)
 #define WS_COUNT(i)
@@ -946,7 +950,9 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         }
 
         WS_LAP(kWsEncode);
-        // ---- 2: the next tile's loads
+        // ---- 2: the next tile's loads.  (Issued EARLIER -- row by row between the lookups, each row into the registers its
+        // lookups had just vacated, when the tile's number was already there -- they made the encoder 7-15 % slower:
+        // tools/ab.py, round 3.  More requests in flight lengthen the queues of a memory system that is busy already.)
         (void)try_load();
         WS_LAP(kWsStore);
 
@@ -2190,6 +2196,12 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
 //         3, 4: the same two with non-temporal stores
 //         5, 6: dwordx4 non-temporal stores in BURSTS: a wave writes the output of `burst` steps (10: a tile's worth, what
 //               the encoder's store wave does; 32) as one contiguous stretch every `burst`-th step
+//         8:    (k_probe_roles) the encoder's DIVISION OF LABOUR, in the geometry the memory system likes best (tools/
+//               ubench_mem.hip, profiles/r03_ubench_roles.txt): ONE workgroup of 15 reader waves + 1 writer wave per CU; a
+//               reader only reads (4 KiB steps, one -- shape 8 -- or two -- shape 9 -- in flight), the writer only writes -- the output of four
+//               rounds of its workgroup as one stretch (dwordx4, non-temporal), paced by the readers through a counter in
+//               LDS.  No wave has loads queued behind its own stores (vector memory operations of a wave return in order),
+//               and few waves keep the queues short: 6.2 TB/s of bytes moved where the per-step shapes reach 5.1-5.4
 // k_probe_copy: a plain 1:1 copy (dwordx4 non-temporal loads and stores), the known-good reference of a read/write mix.
 // ---------------------------------------------------------------------------------------------
 template <int STORE>
@@ -2216,7 +2228,8 @@ __global__ void __launch_bounds__(kThreads) k_probe_rw(const uint4* __restrict__
     for (; t < tiles4k; t += nw, ++it) {
         // the stores of the PREVIOUS step first, then the next step's loads, then the wait for this step's data
         if (STORE && STORE < 5 && t != w0) store(out + (t - nw) * (uint64_t)wpt, wpt);
-        if (STORE >= 5 && it && (it % burst) == 0u) store(out + ((it / burst - 1u) * nw + w0) * (uint64_t)(wpt * burst), wpt * burst);
+        if ((STORE == 5 || STORE == 6) && it && (it % burst) == 0u) store(out + ((it / burst - 1u) * nw + w0) * (uint64_t)(wpt * burst), wpt * burst);
+
         u32x4 na = a, nb = b, nc = c, nd = d;
         if (t + nw < tiles4k) {
             const u32x4* q = src + (t + nw) * 256u + lane;
@@ -2230,11 +2243,74 @@ __global__ void __launch_bounds__(kThreads) k_probe_rw(const uint4* __restrict__
         const uint64_t tl = w0 + ((tiles4k - 1 - w0) / nw) * nw;
         store(out + tl * (uint64_t)wpt, wpt);
     }
-    if (STORE >= 5 && it) {                            // what is left of the last burst
+    if ((STORE == 5 || STORE == 6) && it) {            // what is left of the last burst
         const uint64_t done = (it - 1u) / burst * burst, left = it - done;
         store(out + (((it - 1u) / burst) * nw + w0) * (uint64_t)(wpt * burst), (uint32_t)left * wpt);
     }
     if (acc == 0x12345678u) *sink = acc;
+}
+
+constexpr int kProbeReaders = 15, kProbeRounds = 4;        // k_probe_roles: reader waves per workgroup (+1 writer), rounds per writer burst
+template <int DEPTH>                                        // 4 KiB steps a reader keeps in flight
+__global__ void __launch_bounds__(64 * (kProbeReaders + 1)) k_probe_roles(const uint4* __restrict__ in, uint64_t tiles4k,
+                                                                          uint32_t* __restrict__ out, uint32_t wpt, uint32_t* sink)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int R = kProbeReaders;
+    constexpr uint32_t rounds = kProbeRounds;
+    __shared__ uint32_t steps_read;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) steps_read = 0u;
+    __syncthreads();
+    const uint64_t nr = (uint64_t)gridDim.x * R;                  // reader waves of the grid; the workgroup's round k: steps first + k * nr + {0..R-1}
+    const uint64_t first = (uint64_t)blockIdx.x * R;
+    if (wave < R) {
+        const u32x4* src = (const u32x4*)in;
+        uint32_t acc = 0;
+        u32x4 r[DEPTH][4];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const uint64_t t = first + (uint64_t)wave + (uint64_t)d * nr;
+            if (t < tiles4k) {
+                const u32x4* q = src + t * 256u + lane;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[d][j] = __builtin_nontemporal_load(q + 64 * j);
+            }
+        }
+        for (uint64_t t = first + (uint64_t)wave; t < tiles4k; t += (uint64_t)DEPTH * nr) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const uint64_t td = t + (uint64_t)d * nr;
+                if (td < tiles4k) {
+                    acc += r[d][0].x ^ r[d][1].y ^ r[d][2].z ^ r[d][3].w;       // (waits for step td's data only)
+                    if (lane == 0) __hip_atomic_fetch_add(&steps_read, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint64_t tn = td + (uint64_t)DEPTH * nr;
+                    if (tn < tiles4k) {
+                        const u32x4* q = src + tn * 256u + lane;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[d][j] = __builtin_nontemporal_load(q + 64 * j);
+                    }
+                }
+            }
+        }
+        if (acc == 0x12345678u) *sink = acc;
+    } else {
+        // a burst = the output of `rounds` rounds of the workgroup, one stretch, in a region of its own (the rounds of a
+        // workgroup are not adjacent in the stream)
+        uint32_t k = 0;
+        for (uint64_t t0 = first; t0 < tiles4k; t0 += nr * rounds, k += rounds) {
+            uint32_t nst = 0;
+            for (uint32_t j = 0; j < rounds; ++j) {
+                const uint64_t tj = t0 + (uint64_t)j * nr;
+                if (tj < tiles4k) nst += (uint32_t)(tiles4k - tj < (uint64_t)R ? tiles4k - tj : (uint64_t)R);
+            }
+            // wait until the readers have these rounds' data (the readers cannot fail)
+            while (__hip_atomic_load(&steps_read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)R * k + nst) __builtin_amdgcn_s_sleep(2);
+            uint32_t* dst = out + ((uint64_t)(k / rounds) * gridDim.x + blockIdx.x) * (uint64_t)(R * rounds) * wpt;
+            const uint32_t n = nst * wpt;
+            for (uint32_t q = (uint32_t)lane * 4u; q + 3u < n; q += 256u) __builtin_nontemporal_store((u32x4){k, k, k, k + 1u}, (u32x4*)(dst + q));
+        }
+    }
 }
 
 __global__ void __launch_bounds__(kThreads) k_probe_copy(const uint4* __restrict__ in, uint4* __restrict__ out, uint64_t nvec)

@@ -167,6 +167,72 @@ static void mix(const Ctx& c, const char* name, int bpc, uint32_t wpt, uint32_t 
     fflush(stdout);
 }
 
+
+// ---------------------------------------------------------------- division of labour (the encoder's round-3 shape)
+// Workgroups of R reader waves + 1 writer wave: a reader only reads (one 4 KiB step at a time, DEPTH steps in flight), the
+// writer only writes -- every `rounds` rounds the output of its workgroup's R * rounds steps as one stretch.
+template <int DEPTH>
+__global__ void __launch_bounds__(1024) k_roles(const u32x4* __restrict__ in, uint64_t steps, uint32_t* __restrict__ out, uint32_t wpt,
+                                               int R, uint32_t rounds, uint32_t* sink)
+{
+    __shared__ uint32_t steps_read;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) steps_read = 0u;
+    __syncthreads();
+    const uint64_t nr = (uint64_t)gridDim.x * R, first = (uint64_t)blockIdx.x * R;
+    if (wave < R) {
+        u32x4 r[DEPTH][4];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const uint64_t t = first + wave + (uint64_t)d * nr;
+            if (t < steps) { const u32x4* q = in + t * 256u + lane;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[d][j] = __builtin_nontemporal_load(q + 64 * j); }
+        }
+        for (uint64_t t = first + wave; t < steps; t += (uint64_t)DEPTH * nr) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const uint64_t td = t + (uint64_t)d * nr;
+                if (td < steps) {
+                    acc += r[d][0].x ^ r[d][1].y ^ r[d][2].z ^ r[d][3].w;
+                    if (lane == 0) __hip_atomic_fetch_add(&steps_read, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint64_t tn = td + (uint64_t)DEPTH * nr;
+                    if (tn < steps) { const u32x4* q = in + tn * 256u + lane;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[d][j] = __builtin_nontemporal_load(q + 64 * j); }
+                }
+            }
+        }
+        if (acc == 0x12345678u) *sink = acc;
+    } else if (wave == R) {
+        // round k of the workgroup = steps first + k * nr + {0..R-1}; a burst = `rounds` rounds, stored as one stretch of the
+        // output (bursts of one workgroup are NOT adjacent in the stream unless rounds == 1: each burst gets a region of its own)
+        uint32_t k = 0;
+        for (uint64_t t0 = first; t0 < steps; t0 += nr * rounds, k += rounds) {
+            uint32_t nst = 0;
+            for (uint32_t j = 0; j < rounds; ++j) { const uint64_t tj = t0 + (uint64_t)j * nr; if (tj < steps) nst += (uint32_t)(steps - tj < (uint64_t)R ? steps - tj : (uint64_t)R); }
+            while (__hip_atomic_load(&steps_read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)R * k + nst) __builtin_amdgcn_s_sleep(2);
+            uint32_t* dst = out + ((uint64_t)(k / rounds) * gridDim.x + blockIdx.x) * (uint64_t)(R * rounds) * wpt;
+            const uint32_t n = nst * wpt;
+            for (uint32_t q = (uint32_t)lane * 4u; q + 3u < n; q += 256u) __builtin_nontemporal_store((u32x4){k, k, k, k + 1u}, (u32x4*)(dst + q));
+        }
+    }
+}
+template <int DEPTH>
+static void roles(const Ctx& c, int wgs_per_cu, int R, uint32_t rounds, uint32_t wpt)
+{
+    const uint64_t steps = c.bytes / 4096;
+    float med;
+    const float best = time_best([&] {
+        hipLaunchKernelGGL((k_roles<DEPTH>), dim3(256 * wgs_per_cu), dim3(64 * (R + 1)), 0, 0, c.in, steps, c.out, wpt, R, rounds, c.sink);
+    }, &med);
+    const double wr = (double)wpt * 4.0 / 4096.0;
+    printf("roles %2d readers + 1 writer x %d per CU, d%d, writer bursts of %2u rounds (%5.1f KiB), wpt %3u: %.3f ms (med %.3f)  input %5.0f GB/s  total %5.0f GB/s\n",
+           R, wgs_per_cu, DEPTH, rounds, R * rounds * wpt * 4 / 1024.0, wpt, best, med, c.bytes / best / 1e6, c.bytes * (1 + wr) / best / 1e6);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv)
 {
     const uint64_t gib = argc > 1 ? strtoull(argv[1], 0, 10) : 4;
@@ -177,6 +243,20 @@ int main(int argc, char** argv)
     CK(hipMalloc(&d_out, out_bytes)); CK(hipMemset(d_out, 0, out_bytes)); CK(hipMalloc(&d_sink, 4));
     Ctx c{d_in, d_out, d_sink, bytes};
 
+    if (argc > 2 && atoi(argv[2]) == 3) {
+        for (uint32_t wpt : {172u, 288u, 512u}) {
+            mix<2, 1, 2>(c, "dwordx4 per step", 4, wpt, 0);
+            mix<2, 1, 3>(c, "dwordx4 per step", 4, wpt, 0);
+            mix<2, 1, 2>(c, "burst dwordx4", 4, wpt, 0, 32);
+            for (int wgs : {1, 2}) for (int R : {7, 10, 15}) for (uint32_t rounds : {1u, 4u}) {
+                if (wgs * (R + 1) > 32) continue;
+                roles<1>(c, wgs, R, rounds, wpt);
+                roles<2>(c, wgs, R, rounds, wpt);
+            }
+            roles<2>(c, 4, 3, 1, wpt); roles<2>(c, 4, 3, 4, wpt); roles<2>(c, 4, 7, 1, wpt); roles<1>(c, 4, 7, 1, wpt);
+        }
+        return 0;
+    }
     if (argc > 2 && atoi(argv[2]) == 2) {
         for (int rep = 0; rep < 2; ++rep)
         for (int bpc : {4, 6}) {
