@@ -2004,26 +2004,33 @@ constexpr int kDecWaves   = 16;
 constexpr int kDecThreads = 64 * kDecWaves;
 constexpr int kDecTop     = 4;                 // words (x4 symbols) between two top-ups of the rings
 constexpr int kDecChunk   = 16;                // words per lane between two flushes
-constexpr int kDecRing    = 16;                // ring dwords per lane
+constexpr int kDecRing    = 16;                // ring dwords per lane (+2 mirror slots: slots 16, 17 repeat slots 0, 1)
 constexpr int kDecAhead   = 8;                 // words a ring must hold ahead of the read position at a top-up
 constexpr int kDecStride  = 17;                // LDS words per lane in the output staging area
 static_assert((31 + (kDecTop * 4 - 4) * kDecBits) / 32 + 2 < kDecAhead, "short codes cannot outrun the ring between two top-ups");
 static_assert(kDecAhead + 3 + 4 <= kDecRing, "a top-up never overwrites words still to be read");
 
 struct alignas(16) DecSmem {
-    uint16_t fast[1 << kDecBits];              // (length << 8) | symbol, 0 = a longer code
+    uint16_t fast[1 << kDecBits];              // (symbol << 8) | length, 0 = a longer code.  The length sits in the LOW byte: a
+                                               // 64-bit shift takes its count from the low 6 bits of the entry as it stands
     uint32_t lcode[256];                       // long codes, left-aligned in 32 bits, in order of length
     uint8_t  llen[256], lsym[256];
     uint32_t nlong, pad_[3];
-    uint32_t ring[kDecWaves][kDecRing][64];    // stream words, dword-major
+    uint32_t ring[kDecWaves][kDecRing + 2][64];    // stream words, dword-major; [16], [17] mirror [0], [1]: three consecutive
+                                                   // words are three consecutive slots whatever the read position
     uint32_t stage[kDecWaves][64][kDecStride]; // decoded words
 };
+static_assert(sizeof(DecSmem) <= 160 * 1024, "one decoder workgroup per CU");
 
 __device__ __forceinline__ uint32_t dec_word(const uint32_t* __restrict__ bits, uint64_t total_words, uint64_t wi)
 {
     return wi < total_words ? bits[wi] : 0u;
 }
 
+// The hot loop, per output word (4 symbols): the 64 stream bits at the lane's read position from three consecutive
+// ring slots (one ds_read2st64_b32 + one ds_read_b32; two 64-bit shifts), then four times {table index from the top 13
+// bits (two instructions), ds_read_u16, v_perm (symbol into the word), 64-bit shift by the entry itself, SDWA add of its
+// low byte to the position}: 8 vector instructions per symbol where round 2's loop took 15.7.
 __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restrict__ bits, uint64_t total_bits,
                                                         const uint64_t* __restrict__ offsets, uint64_t num_segs,
                                                         const uint32_t* __restrict__ cw, const uint32_t* __restrict__ cl,
@@ -2031,7 +2038,7 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dec_smem_raw[];
     DecSmem& sm = *reinterpret_cast<DecSmem*>(dec_smem_raw);
-    // ---- tables.  Short codes: every table index that starts with the code gets (length << 8) | symbol; the indices
+    // ---- tables.  Short codes: every table index that starts with the code gets (symbol << 8) | length; the indices
     // of one symbol are filled by all threads together (a 1-bit code owns half the table).  Long codes: a list ordered
     // by length (the likelier first), searched linearly.
     __shared__ uint32_t t_len[256], t_code[256];
@@ -2046,7 +2053,7 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
         const uint32_t len = t_len[sy];
         if (len >= 1u && len <= (uint32_t)kDecBits) {
             const uint32_t base = t_code[sy] << (kDecBits - len), n = 1u << (kDecBits - len);
-            for (uint32_t i = threadIdx.x; i < n; i += kDecThreads) sm.fast[base + i] = (uint16_t)((len << 8) | (uint32_t)sy);
+            for (uint32_t i = threadIdx.x; i < n; i += kDecThreads) sm.fast[base + i] = (uint16_t)(((uint32_t)sy << 8) | len);
         }
     }
     if (threadIdx.x < 256) {
@@ -2068,6 +2075,22 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
     const uint32_t nl = sm.nlong;
     uint32_t (*const ring)[64] = sm.ring[wave];
     uint32_t (*const my)[kDecStride] = sm.stage[wave];
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+    const uint32_t ring_lane = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&ring[0][lane];   // LDS byte address of slot 0
+    const uint32_t fast_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&sm.fast[0];
+    // a symbol of a long code (or of an invalid stream: then symbol 0, one bit) from the 32 bits at the read position
+    auto slow_symbol = [&](uint32_t win, uint32_t& sym, uint32_t& len) {
+        const uint32_t e = sm.fast[win >> (32 - kDecBits)];
+        sym = e >> 8; len = e & 255u;
+        if (len == 0u) {
+            len = 1u; sym = 0u;
+            for (uint32_t q = 0; q < nl; ++q) {
+                const uint32_t L = sm.llen[q];
+                if (((win ^ sm.lcode[q]) >> (32u - L)) == 0u) { len = L; sym = sm.lsym[q]; break; }
+            }
+        }
+    };
     // a wave owns 64 consecutive segments; all its lanes run the same number of chunks (a wave-uniform loop)
     for (uint64_t seg0 = ((uint64_t)blockIdx.x * kDecWaves + wave) * 64; seg0 < num_segs; seg0 += (uint64_t)gridDim.x * kDecWaves * 64) {
         const uint64_t seg = seg0 + (uint64_t)lane;
@@ -2101,28 +2124,31 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
                                v.z = dec_word(bits, total_words, wi + 2); v.w = dec_word(bits, total_words, wi + 3); }
                         const uint32_t sl = have & (kDecRing - 1);
                         ring[sl][lane] = v.x; ring[sl + 1][lane] = v.y; ring[sl + 2][lane] = v.z; ring[sl + 3][lane] = v.w;
+                        if (sl == 0u) { ring[kDecRing][lane] = v.x; ring[kDecRing + 1][lane] = v.y; }       // the mirror slots
                         have += 4;
                     }
                 }
                 // (same lane, same wave: LDS operations complete in order, no barrier)
-#pragma unroll 1
+#pragma unroll
                 for (int w = 0; w < kDecTop; ++w) {
                     // four symbols per bit buffer, straight-line and branch-free: a long code reads as length 0
                     const uint32_t p0 = pb, kk = pb >> 5, sh = pb & 31u;
-                    const uint32_t w0 = ring[kk & (kDecRing - 1)][lane], w1 = ring[(kk + 1) & (kDecRing - 1)][lane],
-                                   w2 = ring[(kk + 2) & (kDecRing - 1)][lane];
-                    uint64_t buf = ((((uint64_t)w0 << 32) | (uint64_t)w1) << sh) | (((uint64_t)w2 << sh) >> 32);
-                    uint32_t word = 0, len = 0;
+                    lds_cu32* const rp = (lds_cu32*)(uintptr_t)(ring_lane + ((kk & (uint32_t)(kDecRing - 1)) << 8));
+                    const uint32_t w0 = rp[0], w1 = rp[64], w2 = rp[128];
+                    uint64_t buf = ((((uint64_t)w0 << 32) | (uint64_t)w1) << sh) & 0xffffffff00000000ull;
+                    buf |= ((((uint64_t)w1 << 32) | (uint64_t)w2) << sh) >> 32;
+                    uint32_t word = 0, e = 0;
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const uint32_t e = sm.fast[(uint32_t)(buf >> (64 - kDecBits))];
-                        len  = e >> 8;
-                        word = __builtin_amdgcn_perm(word, e, 0x06050400u);   // (word << 8) | (e & 255): most significant byte first (cpuencode.cpp:28)
-                        buf <<= len; pb += len;
+                        const uint32_t idx2 = ((uint32_t)(buf >> 32) >> (31 - kDecBits)) & ((2u << kDecBits) - 2u);   // 2 x the top 13 bits
+                        e    = *(lds_cu16*)(uintptr_t)(fast_base + idx2);
+                        word = __builtin_amdgcn_perm(word, e, 0x06050401u);   // (word << 8) | symbol: most significant byte first (cpuencode.cpp:28)
+                        buf <<= (e & 63u);                                    // (lengths <= 13: the low 6 bits of the entry are the length)
+                        pb += e & 255u;
                     }
                     // a long code leaves the buffer where it is, so every lookup behind it reads the same entry: the LAST
-                    // length is 0 exactly when any of the four was
-                    const bool redo = len == 0u || kk + 2u >= have;          // a long code, or the lane is past its ring
+                    // entry is 0 exactly when any of the four was
+                    const bool redo = e == 0u || kk + 2u >= have;            // a long code, or the lane is past its ring
                     if (__any(redo)) {
                         const bool far = redo && kk + 6u >= have;            // (even a redo from the ring could run out of it)
                         if (redo && !far) {          // cold: this lane decodes the word again, symbol by symbol, from its ring
@@ -2132,15 +2158,8 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
                                 const uint32_t k2 = pb >> 5, s2 = pb & 31u;
                                 const uint32_t x0 = ring[k2 & (kDecRing - 1)][lane], x1 = ring[(k2 + 1) & (kDecRing - 1)][lane];
                                 const uint32_t win2 = (uint32_t)(((((uint64_t)x0 << 32) | (uint64_t)x1) << s2) >> 32);   // 32 bits: a whole code
-                                const uint32_t e = sm.fast[win2 >> (32 - kDecBits)];
-                                uint32_t sym = e & 255u, len = e >> 8;
-                                if (len == 0u) {     // a long code (or an invalid stream: then symbol 0, one bit)
-                                    len = 1u; sym = 0u;
-                                    for (uint32_t q = 0; q < nl; ++q) {
-                                        const uint32_t L = sm.llen[q];
-                                        if (((win2 ^ sm.lcode[q]) >> (32u - L)) == 0u) { len = L; sym = sm.lsym[q]; break; }
-                                    }
-                                }
+                                uint32_t sym, len;
+                                slow_symbol(win2, sym, len);
                                 pb += len;
                                 word = (word << 8) | sym;
                             }
@@ -2150,16 +2169,8 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
                                 pb = p0; word = 0;
 #pragma unroll 1
                                 for (int b = 0; b < 4; ++b) {
-                                    const uint32_t win2 = (uint32_t)(bits64_at(pb) >> 32);
-                                    const uint32_t e = sm.fast[win2 >> (32 - kDecBits)];
-                                    uint32_t sym = e & 255u, len = e >> 8;
-                                    if (len == 0u) {
-                                        len = 1u; sym = 0u;
-                                        for (uint32_t q = 0; q < nl; ++q) {
-                                            const uint32_t L = sm.llen[q];
-                                            if (((win2 ^ sm.lcode[q]) >> (32u - L)) == 0u) { len = L; sym = sm.lsym[q]; break; }
-                                        }
-                                    }
+                                    uint32_t sym, len;
+                                    slow_symbol((uint32_t)(bits64_at(pb) >> 32), sym, len);
                                     pb += len;
                                     word = (word << 8) | sym;
                                 }
