@@ -198,7 +198,7 @@ hvlc_ctx*  g_default_ctx = nullptr;
 
 extern "C" {
 
-const char* hvlc_version(void) { return "hvlc 0.2 (gfx950)"; }
+const char* hvlc_version(void) { return "hvlc 0.3 (gfx950)"; }
 
 const char* hvlc_status_string(int s)
 {

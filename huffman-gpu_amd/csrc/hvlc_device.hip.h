@@ -1710,9 +1710,11 @@ k_encode(EncodeParams p)
         const bool permuted = !(c0 <= c1 || c0 <= (1u << 24) / 32u);
         if (tid < 256)
             sm.lut[permuted ? lut_slot((uint32_t)tid) : (uint32_t)tid] = make_uint2(len ? (code & ((1u << len) - 1u)) : 0u, len);
-        {   // everything behind the table starts as zero: rings, records, counters
-            uint4* z = reinterpret_cast<uint4*>(&sm.ring[0][0]);
-            const uint32_t nvec = (uint32_t)((offsetof(Smem, len_tmp) - sizeof(sm.lut)) / 16u);
+        {   // records and counters start as zero.  (Not the rings: a data wave zeroes the words it takes before it packs
+            // into them, the slow path its scratch words -- 70 KiB less to write per workgroup and launch.)
+            static_assert(offsetof(Smem, wrec) % 16 == 0 && offsetof(Smem, len_tmp) % 16 == 0, "zeroed as 16-byte vectors");
+            uint4* z = reinterpret_cast<uint4*>(&sm.wrec[0][0]);
+            const uint32_t nvec = (uint32_t)((offsetof(Smem, len_tmp) - offsetof(Smem, wrec)) / 16u);
             for (uint32_t i = (uint32_t)tid; i < nvec; i += (uint32_t)kEncThreads) z[i] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();                                  // the only workgroup-wide barriers (three): LDS initialised
