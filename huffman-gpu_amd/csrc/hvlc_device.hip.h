@@ -1014,13 +1014,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             if (lane == 0) *reinterpret_cast<uint2*>(&sm.wrec[slot][wave].start) = make_uint2(start, need);
             zero_words(ring + start, need / 4u, lane);       // (what an older part left there; the store wave only reads)
             uint32_t* const st = ring + start + 1;
-#ifdef HVLC_ABL_NO_PACK
-            if (false) {
-#pragma unroll
-                for (int r = 0; r < kRows; ++r) asm volatile("" :: "v"(acc[r]), "v"(incl[r]));
-#else
             if (!HVLC_DBG(p, kDbgNoPack)) {
-#endif
                 const uint32_t longest = max(max(tot[0], tot[1]), max(tot[2], tot[3]));
                 if (!__any(longest > 64u)) {
 #pragma unroll
