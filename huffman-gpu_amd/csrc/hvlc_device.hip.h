@@ -623,6 +623,21 @@ __device__ __forceinline__ bool part_is_full(const EncodeParams& p, uint32_t til
     return (uint64_t)tile * kTileWords + (uint64_t)(wave + 1) * (kRows * kSegWords) <= p.num_words;
 }
 
+// Does it lie completely behind the end of the input?  (Only parts of the last tile can: the ones behind the part the
+// input ends in.  They hold no bits and nobody packs, stores or waits for them.)
+__device__ __forceinline__ bool part_is_empty(const EncodeParams& p, uint32_t tile, int wave)
+{
+    return (uint64_t)tile * kTileWords + (uint64_t)wave * (kRows * kSegWords) >= p.num_words;
+}
+// Parts of `tile` that hold input: kDataWaves, fewer for the last tile.  The last of them ends the stream (it stores
+// the open word and the total).
+__device__ __forceinline__ int parts_of_tile(const EncodeParams& p, uint32_t tile)
+{
+    if (tile != (uint32_t)(p.num_tiles - 1)) return kDataWaves;
+    const uint32_t words = (uint32_t)(p.num_words - (uint64_t)tile * kTileWords);      // 1 .. kTileWords
+    return (int)((words + (uint32_t)(kRows * kSegWords) - 1u) / (uint32_t)(kRows * kSegWords));
+}
+
 __device__ __forceinline__ int valid_words(const EncodeParams& p, uint64_t wbase)
 {
     return wbase >= p.num_words ? 0 : (p.num_words - wbase >= 4 ? 4 : (int)(p.num_words - wbase));
@@ -778,7 +793,7 @@ __device__ __forceinline__ bool slow_part(const EncodeParams& p, Smem& sm, uint3
     uint64_t G = uni64(sm.ts[slot].prefix) + (uint64_t)uni(sm.wrec[slot][wave].base);
     uint32_t carry = 0;
     zero_words(ring, (kRowWordsMax + 3u) / 4u, lane);          // (packed parts leave their words behind: the ring is empty, not clean)
-    const bool last_part = (tile == (uint32_t)(p.num_tiles - 1)) && wave == kDataWaves - 1;
+    const bool last_part = (tile == (uint32_t)(p.num_tiles - 1)) && wave == parts_of_tile(p, tile) - 1;   // the part the input ends in
     const uint32_t* in32 = (const uint32_t*)p.in;
 #pragma unroll 1
     for (int r = 0; r < kRows; ++r) {
@@ -1002,7 +1017,13 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         }
 
         WS_LAP(kWsArrive);
-        if (!slow) {
+        if (!full && part_is_empty(p, cur, wave)) {
+            // behind the end of the input (cold): the part has arrived with zero bits; nothing to pack, store or wait for
+            if (lane == 0) *reinterpret_cast<uint2*>(&sm.wrec[slot][wave].start) = make_uint2(0u, 0u);
+            ++n_packed;
+            if (lane == 0) lds_rel(&sm.packed[wave], n_packed);
+            head = 0;
+        } else if (!slow) {
             // ---- 4: ring words, pack, hand over
             uint32_t start;
             if ((start = ring_place(sm, wave, head, n_packed, freed, need)) == kNoRoom) {
@@ -1125,8 +1146,9 @@ __device__ __forceinline__ bool store_tile_generic(const EncodeParams& p, Smem& 
     bool pend = false;               // prev's last, partial block [block start, prev's end) waits for the next part's first words
     bool prev_fast = false;          // the part in front (of this tile) was a packed part: `carry` is mine to hand on
     WaveWait w;
+    const int nparts = parts_of_tile(p, tile);                 // (the last tile: the parts behind the end of the input are nobody's business)
 #pragma unroll 1
-    for (int wv = 0; wv < kDataWaves; ++wv) {
+    for (int wv = 0; wv < nparts; ++wv) {
         const uint32_t T    = uni(sm.wrec[slot][wv].bits);
         const uint64_t G    = P + (uint64_t)uni(sm.wrec[slot][wv].base);
         if (!part_is_fast(p, tile, wv, T)) {
@@ -1152,7 +1174,7 @@ __device__ __forceinline__ bool store_tile_generic(const EncodeParams& p, Smem& 
 
         // the part's words: [lo, hi); the last part of the stream also stores the open word, zero padded, and the zero
         // word cpu_vlc_encode leaves behind when the stream ends on a word boundary (cpuencode.cpp:39)
-        const bool last = last_tile && wv == kDataWaves - 1;
+        const bool last = last_tile && wv == nparts - 1;
         const uint64_t lo = c.ow;
         uint64_t hi = (G + T) >> 5;
         if (last) {
@@ -1167,7 +1189,7 @@ __device__ __forceinline__ bool store_tile_generic(const EncodeParams& p, Smem& 
             if (lane == 0) atomicOr(p.status(), kFlagCapacity);
             hi = cap > lo ? cap : lo;
         }
-        const bool more = wv + 1 < kDataWaves && hi == ((G + T) >> 5) &&
+        const bool more = wv + 1 < nparts && hi == ((G + T) >> 5) &&
                           part_is_fast(p, tile, wv + 1, uni(sm.wrec[slot][wv + 1].bits));   // the next part continues this one's last block
         if (!HVLC_DBG(p, kDbgNoStore)) {
             // first block: from the block boundary at or below lo
@@ -1636,6 +1658,7 @@ k_encode(EncodeParams p)
     // only the last wave to leave increments it); zero this workgroup's slice of what the previous call used of the
     // OTHER half -- the next launch starts there
     uint32_t* const ctl = p.ctl();
+    TL(p, 0, 7, blockIdx.x == 0 && tid == 0);                 // (experiment builds: workgroup 0 enters the kernel)
     // (the table's loads go out first: they do not depend on the control block, whose load everything else waits for)
     uint32_t len = 0, code = 0;
     if (tid < 256) { len = p.cl[tid]; code = p.cw[tid]; }
