@@ -160,6 +160,8 @@ enum : uint32_t { kDbgNoLookback = 1u, kDbgNoStore = 2u, kDbgNoPack = 4u, kDbgNo
 #define HVLC_DBG(p, bit) (((p).dbg & (bit)) != 0u)
 #define TL(p, tile, k, cond) do { if ((p).dbg_tl && (cond)) (p).dbg_tl[(uint64_t)(tile) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define TLV(p, tile, k, v, cond) do { if ((p).dbg_tl && (cond)) (p).dbg_tl[(uint64_t)(tile) * 8 + (k)] = (v); } while (0)
+// stamps of workgroup 0's prologue and first tile, in the row behind the last tile's (tools/one_tile_timeline.py)
+#define TLX(p, k, cond) do { if ((p).dbg_tl && blockIdx.x == 0 && (cond)) (p).dbg_tl[(p).num_tiles * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // per-wave time accounting of a data wave (tools/wave_stats.py): shader clocks per phase and per cause of waiting
 enum { kWsEncode = 0, kWsStore, kWsArrive, kWsPack, kWsWaitTicket, kWsWaitDrain, kWsWaitSlot, kWsWaitRing, kWsWaitSlow, kWsWaitTail,
        kWsTotal, kWsTiles, kWsNWaits };
@@ -179,6 +181,7 @@ struct WaveStats {
 #else
 #define TL(p, tile, k, cond)
 #define TLV(p, tile, k, v, cond)
+#define TLX(p, k, cond)
 #ifdef HVLC_ABL_MASK
 #define HVLC_DBG(p, bit) (((HVLC_ABL_MASK) & (bit)) != 0u)      // (tools/: a compile-time ablation without the instrumentation)
 #else
@@ -898,7 +901,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             WaveWait w;
             for (;;) {
                 if (n_final == ~0u) n_final = lds_rlx(&sm.n_final);      // (read BEFORE the ticket count: once set, every ticket is visible)
-                if (try_load()) break;
+                if (try_load()) { TLX(p, 3, wave == 0 && lane == 0 && n_loaded == 1u); break; }     // first tile number seen, loads issued
                 if (n_final != ~0u && n_loaded >= n_final) { WS_LAP(kWsWaitTicket); WS_DUMP(p, wave, lane); return; }   // the tickets ran out: nothing left to encode
                 if (!w.step(p, sm, lane)) return;
             }
@@ -909,6 +912,9 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         const bool full = cur != last_tile || part_is_full(p, cur, wave);   // (only the part the input ends in, and the empty ones behind it, are not)
 
         // ---- 1: lookups, concatenation, scan (registers only)
+#ifdef HVLC_EXPERIMENT
+        if (n_packed == 0u && wave == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TLX(p, 4, lane == 0); }   // the first tile's words are here
+#endif
         uint64_t acc[kRows];
         uint32_t tot[kRows], incl[kRows], rowbase[kRows];
         if (full) {
@@ -965,6 +971,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         }
 
         WS_LAP(kWsEncode);
+        TLX(p, 5, wave == 0 && lane == 0 && n_packed == 0u);           // the first part is encoded and scanned
         // ---- 2: the next tile's loads.  (Issued EARLIER -- row by row between the lookups, each row into the registers its
         // lookups had just vacated, when the tile's number was already there -- they made the encoder 7-15 % slower:
         // tools/ab.py, round 3.  More requests in flight lengthen the queues of a memory system that is busy already.)
@@ -1248,15 +1255,29 @@ __device__ __forceinline__ bool store_tile_generic(const EncodeParams& p, Smem& 
 // starts in (a junction with the part in front, or the tile's ragged first block) and of its first four whole blocks
 // go out TOGETHER, then the shifts, then the stores.  The data waves zero their ring words themselves (when they take
 // them), so nothing is left to do behind the stores.  False = abort.
-__device__ __forceinline__ bool store_tile(const EncodeParams& p, Smem& sm, uint32_t n, int lane)
+// LAST: the stream's last tile (a second copy of the code, so that the common one keeps its constant trip counts): its
+// full parts go the same way -- the tail of every launch --; the part the input ends in, if it is not a full one, stores
+// itself behind them (`tail_slow`), otherwise the last full part closes the stream.
+template <bool LAST>
+__device__ __forceinline__ bool store_tile_fast(const EncodeParams& p, Smem& sm, uint32_t n, int lane_in)
 {
+    const int lane = LAST ? lane_id_fresh() : lane_in;     // (the cold copy: nothing of it is an invariant of the store wave's loop)
     const uint32_t slot = n % kSlots;
     const uint32_t tile = uni(sm.tq[n % kTq]);
-    const int wvl = lane < kDataWaves ? lane : kDataWaves - 1;
+    int nfast = kDataWaves;
+    bool tail_slow = false, stream_end = false;
+    if (LAST) {
+        const int np = parts_of_tile(p, tile);
+        tail_slow  = !part_is_full(p, tile, np - 1);
+        stream_end = !tail_slow;
+        nfast      = tail_slow ? np - 1 : np;
+        if (nfast == 0) return store_tile_generic(p, sm, n, lane);
+    }
+    const int wvl = lane < nfast ? lane : nfast - 1;
     const WaveRec& rec = sm.wrec[slot][wvl];
     const uint32_t Tl = rec.bits, basel = rec.base;
     uint32_t pk = __hip_atomic_load(&sm.packed[wvl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const bool plain = tile != (uint32_t)(p.num_tiles - 1) && Tl >= 32u && ring_need(Tl) <= kWaveRing;
+    const bool plain = Tl >= 32u && ring_need(Tl) <= kWaveRing;
     if (!__all(plain)) return store_tile_generic(p, sm, n, lane);
     const uint64_t P  = uni64(sm.ts[slot].prefix);
     const uint32_t pt = uni(sm.ts[slot].pred_tail);
@@ -1270,24 +1291,30 @@ __device__ __forceinline__ bool store_tile(const EncodeParams& p, Smem& sm, uint
 #endif
     const uint32_t startl = rec.start;                                      // valid once packed
     const uint64_t Gl = P + (uint64_t)basel;
-    const uint64_t Gend = lane_value64(Gl + Tl, kDataWaves - 1);
-    if ((Gend >> 5) > p.out_cap) return store_tile_generic(p, sm, n, lane);   // (capacity overrun: the general form reports it)
+    const uint64_t Gend = lane_value64(Gl + Tl, (uint32_t)(nfast - 1));
+    // words of the stream up to the end of these parts; the stream's end also takes the open word, zero padded, and the
+    // zero word cpu_vlc_encode leaves behind when the stream ends on a word boundary (cpuencode.cpp:39)
+    uint64_t wend = Gend >> 5;
+    if (LAST && stream_end) wend = ((Gend + 31u) >> 5) + ((Gend & 31u) == 0u ? 1u : 0u);
+    if (wend > p.out_cap) return store_tile_generic(p, sm, n, lane);          // (capacity overrun: the general form reports it)
     uint32_t* const sbl = &sm.ring[wvl][startl];
     // the 32 stream bits behind every part (its own: it holds at least a word), handed to the part behind it as carry word
+    uint32_t cout;
     {
         const uint32_t wi = Tl >> 5, sh = Tl & 31u;
         const uint32_t hi = sbl[wi], lo = sbl[wi + 1];
-        const uint32_t cout = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
+        cout = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
         uint32_t cin = (uint32_t)__shfl_up((int)cout, 1);
         if (lane == 0) cin = pt;
-        if (lane < kDataWaves) sbl[0] = cin;
+        if (lane < nfast) sbl[0] = cin;
     }
     // segment offsets: lane l = segment l of the tile
     if (p.offsets && lane < kSegsPerTile && !HVLC_DBG(p, kDbgNoOffsets)) {
         const WaveRec& r = sm.wrec[slot][lane / kRows];
         const uint32_t rr = (uint32_t)lane % (uint32_t)kRows;
         const uint32_t rel = r.base + (rr ? (&r.base)[rr] : 0u);
-        ABL_STORE(P + rel, &p.offsets[(uint64_t)tile * kSegsPerTile + (uint64_t)lane]);
+        const uint64_t seg = (uint64_t)tile * kSegsPerTile + (uint64_t)lane;
+        if (!LAST || seg < p.num_segs) ABL_STORE(P + rel, &p.offsets[seg]);
     }
     if (HVLC_DBG(p, kDbgNoStore)) return true;
     // ---- the stream: positions in words relative to the tile's first word ow0
@@ -1296,7 +1323,7 @@ __device__ __forceinline__ bool store_tile(const EncodeParams& p, Smem& sm, uint
     const uint32_t mis0 = ((uint32_t)((uintptr_t)p.out >> 2) + (uint32_t)ow0) & (kBlockWords - 1u);   // block boundaries: r with (r + mis0) % 64 == 0
     const int32_t  rl   = (int32_t)(uint32_t)((Gl >> 5) - ow0);             // the part's first word
     const uint32_t sl   = (uint32_t)Gl & 31u;
-    const int32_t  rend = (int32_t)(uint32_t)((Gend >> 5) - ow0);
+    const int32_t  rend = (int32_t)(uint32_t)(wend - ow0);
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     const uint32_t sbaddr = (uint32_t)(uintptr_t)(lds_u32*)sbl;             // LDS byte address of the part's carry word
     auto lds_at = [](uint32_t byte_addr) { return (const uint32_t*)(lds_u32*)(uintptr_t)byte_addr; };
@@ -1314,7 +1341,7 @@ __device__ __forceinline__ bool store_tile(const EncodeParams& p, Smem& sm, uint
         q.lo = lo;
         q.sb = (uint32_t)__builtin_amdgcn_readlane((int)sbaddr, wv);
         q.sh = (uint32_t)__builtin_amdgcn_readlane((int)sl, wv);
-        q.hi = wv + 1 < kDataWaves ? __builtin_amdgcn_readlane(rl, wv + 1) : rend;
+        q.hi = wv + 1 < nfast ? __builtin_amdgcn_readlane(rl, wv + 1) : rend;
         q.B0 = lo - (int32_t)(((uint32_t)lo + mis0) & (kBlockWords - 1u));  // block 0 = the block the part starts in: [B0, B0 + 64)
         q.e0 = q.hi < q.B0 + 64 ? q.hi : q.B0 + 64;
         q.nblk = q.hi >= q.B0 + 128 ? (q.hi - (q.B0 + 64)) / 64 : 0;        // whole blocks behind block 0
@@ -1334,7 +1361,7 @@ __device__ __forceinline__ bool store_tile(const EncodeParams& p, Smem& sm, uint
         // the part's last, partial block [Bl, hi) is left to the part behind it (a junction) when there is one and the
         // block lies behind block 0
         const int32_t Bl = q.hi - (int32_t)(((uint32_t)q.hi + mis0) & (kBlockWords - 1u));
-        pend = wv + 1 < kDataWaves && Bl > q.B0 && Bl < q.hi;
+        pend = wv + 1 < nfast && Bl > q.B0 && Bl < q.hi;
         plo = lo; psb = q.sb; psh = q.sh;
     };
     auto consume = [&](const Batch& c, bool more) {
@@ -1366,18 +1393,38 @@ __device__ __forceinline__ bool store_tile(const EncodeParams& p, Smem& sm, uint
             }
         }
     };
-    static_assert(kDataWaves % 2 == 0, "two register sets take turns");
-    Batch A, B;
+    Batch A, B;                                                              // two register sets take turns
     issue(0, 0, A);
 #pragma unroll 1
-    for (int wv = 0; wv < kDataWaves; wv += 2) {
-        issue(wv + 1, A.hi, B);
-        consume(A, true);
-        const bool more = wv + 2 < kDataWaves;
+    for (int wv = 0; wv < nfast; wv += 2) {
+        const bool second = wv + 1 < nfast;
+        if (second) issue(wv + 1, A.hi, B);
+        consume(A, second);
+        if (!second) break;
+        const bool more = wv + 2 < nfast;
         if (more) issue(wv + 2, B.hi, A);
         consume(B, more);
     }
+    if (LAST && stream_end && lane == 0) {
+        p.result()[0] = Gend;
+        if (p.total_bits) *p.total_bits = Gend;
+    }
+    if (LAST && tail_slow) {
+        // the part the input ends in stores itself (slow_part): give its wave the 31 bits in front of it, wait for it
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cout, nfast - 1);
+        if (lane == 0) lds_rel(&sm.wrec[slot][nfast - 1].tail, kValid32 | (c & 0x7fffffffu));
+        wake_workgroup();
+        WaveWait w;
+        while (!(lds_acq(&sm.wrec[slot][nfast].tail) & kValid32))
+            if (!w.step(p, sm, lane)) return false;
+    }
     return true;
+}
+
+__device__ __forceinline__ bool store_tile(const EncodeParams& p, Smem& sm, uint32_t n, int lane)
+{
+    if (uni(sm.tq[n % kTq]) == (uint32_t)(p.num_tiles - 1)) return store_tile_fast<true>(p, sm, n, lane);
+    return store_tile_fast<false>(p, sm, n, lane);
 }
 
 __device__ __forceinline__ void encode_store_wave(const EncodeParams& p, Smem& sm, int lane)
@@ -1706,7 +1753,9 @@ k_encode(EncodeParams p)
             if (bad && blockIdx.x == 0) atomicOr(p.status(), kFlagTable);
             sm.len_tmp[tid] = (uint8_t)len;                          // (one load of the table per workgroup, not per wave)
         }
+        TLX(p, 0, tid == 0);                                         // the table's loads are back
         __syncthreads();
+        TLX(p, 1, tid == 0);
         uint32_t c0, c1;
         {
             uint32_t m0 = 0, t0 = 0, m1 = 0, t1 = 0;
@@ -1737,6 +1786,7 @@ k_encode(EncodeParams p)
         __syncthreads();                                  // the only workgroup-wide barriers (three): LDS initialised
         if (tid == 0) { sm.n_final = ~0u; sm.tix_ahead = (uint32_t)kTixAhead; }
         __syncthreads();
+        TLX(p, 2, tid == 0);                                         // LDS is set up: the roles part
 #ifdef HVLC_PRIO_YOUNG
         if (wave >= 4 && wave < kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_YOUNG);
 #endif

@@ -113,6 +113,21 @@ def test_ragged_sizes_vs_oracle(enc, nwords, kind):
     _check(enc, x, cw, cl, f"{kind}/{nwords}")
 
 
+@pytest.mark.parametrize("kind", ["short", "any", "len4"])
+def test_every_shape_of_the_last_tile(enc, kind):
+    """The stream's last tile takes its own way through the store wave: its full parts (4 KiB each) are stored like any
+    tile's, the part the input ends in stores itself unless it is a full one (then the last full part closes the
+    stream), parts behind the end are nobody's.  Sizes around every part and tile boundary (a tile = 10240 words);
+    with the 4-bit table every part ends on a word boundary (the zero word behind the stream, cpuencode.cpp:39)."""
+    rng = np.random.default_rng(4242 + len(kind))
+    cw, cl = random_table(rng, kind)
+    sizes = [1024, 1025, 2047, 2048, 2049, 9215, 9216, 9217, 10239, 10240, 10241, 11264, 11265, 20480, 20481,
+             10240 * 64, 10240 * 64 + 1, 10240 * 65 - 1024, 10240 * 65 - 1023]
+    for nwords in sizes:
+        x = rng.integers(0, 1 << 32, nwords, dtype=np.uint64).astype(np.uint32)
+        _check(enc, x, cw, cl, f"{kind}/{nwords}")
+
+
 @pytest.mark.parametrize("kind", ["all31", "alt1_31", "zeros", "allzero", "len4", "len16", "len17"])
 def test_adversarial_tables(enc, kind):
     """All-31-bit codes (496 bits per 16 symbols: general path), alternating 1/31, mostly/all

@@ -23,18 +23,20 @@ for kib in [int(x) for x in sys.argv[1:]] or [1, 40, 80, 2560, 20480, 262144]:
     n = kib << 10
     ntiles = (n + 40959) // 40960
     call = lambda: e.encode_ptr(d_all.data_ptr(), n // 4, d_tab.data_ptr(), d_tab.data_ptr() + 1024, out.data_ptr(), out.numel(), offs.data_ptr(), 0)
-    tl = torch.zeros(ntiles * 8, dtype=torch.int64, device="cuda")
+    tl = torch.zeros((ntiles + 1) * 8, dtype=torch.int64, device="cuda")
     L.hvlc_debug_set_timeline(C.c_void_p(tl.data_ptr()))
     for _ in range(5): call()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(50): call()
     e1.record(); e1.synchronize()
-    t = tl.cpu().numpy().reshape(ntiles, 8).astype(np.float64)
+    tx = tl.cpu().numpy().reshape(ntiles + 1, 8).astype(np.float64); t, x = tx[:ntiles], tx[ntiles]
     t0 = t[0, 7]
     print(f"{kib} KiB: {ntiles} tiles, {e0.elapsed_time(e1) / 50 * 1000:.1f} us per call (events, 50 calls back to back)")
     for name, row in (("tile 0", t[0]), ("last tile", t[-1])) if ntiles > 1 else (("tile 0", t[0]),):
         print("   " + name + ": " + "  ".join(f"{NAMES[k]} {(row[k] - t0) / 100:.2f}" for k in (0, 1, 2, 3, 4, 5, 6) if row[k] > 0))
+    XN = ["table loaded", "barrier 1", "LDS set up", "wave 0: first tile number, loads issued", "first words here", "first part encoded"]
+    print("   workgroup 0: " + "  ".join(f"{XN[k]} {(x[k] - t0) / 100:.2f}" for k in range(6) if x[k] > 0))
     if ntiles > 1:
         print(f"   latest stamp of any tile: {(t[:, :7].max() - t0) / 100:.2f} us after wg0's entry; first 'bits published' of any tile {(t[:, 0][t[:, 0] > 0].min() - t0) / 100:.2f}")
     L.hvlc_debug_set_timeline(None)
