@@ -275,7 +275,9 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t x)
 // Bounded wait: ~every 1024 polls look at the 100 MHz real-time counter and at the global
 // status word; give up (and make everybody else give up) after timeout_ticks.
 #ifndef HVLC_WAIT_SLEEP
-#define HVLC_WAIT_SLEEP 64       // x64 clocks per look of a WAITING wave at its LDS words (s_wakeup ends the sleep early)
+#define HVLC_WAIT_SLEEP 64       // x64 clocks per look of a WAITING wave at its LDS words (s_wakeup ends the sleep early).
+                                 // (16 or 8, or a few short sleeps before the long ones against wake-ups that found nobody
+                                 // asleep yet: 0.4-3 % SLOWER -- looks cost LDS time and issue slots: tools/ab.py, round 3)
 #endif
 struct Spin {
     uint64_t t0 = 0;
@@ -1499,7 +1501,7 @@ struct LeaderDuty {
     uint32_t excl_in = 0;       // per lane: bits of the group's tiles before tile 64g+lane
 };
 
-__device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& sm, int lane, uint32_t first_ticket)
+__device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& sm, int lane, uint32_t first_ticket, bool first_published)
 {
     // lanes 2q, 2q+1 poll the record of the tile in poll slot q (workgroup-local tile n uses slot n % kMaxPoll):
     // byte offset from p.recs() of the 8 bytes this lane reads (record 0 until a slot is started)
@@ -1512,8 +1514,8 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
     const uint32_t ntiles = (uint32_t)p.num_tiles, last_tile = ntiles - 1u;
     // tickets: draw k of class cls is tile C*k + (cls + k) % C
     const uint32_t cls = blockIdx.x % (uint32_t)kTicketClasses;
-    uint32_t n_tix = 0, n_final = ~0u;  // tiles drawn; the total once the tickets ran out
-    bool     tix_inflight = true;       // (the first draw was made in the kernel's prologue)
+    uint32_t n_tix = first_published ? 1u : 0u, n_final = ~0u;  // tiles drawn; the total once the tickets ran out
+    bool     tix_inflight = !first_published;   // (the first draw was made in the kernel's prologue, and handed on there if it was a tile)
     uint32_t tix_k = first_ticket;      // lane 0: the value a ticket draw returned (valid one round later)
 
     while (n_done < n_final) {
@@ -1785,6 +1787,22 @@ k_encode(EncodeParams p)
         }
         __syncthreads();                                  // the only workgroup-wide barriers (three): LDS initialised
         if (tid == 0) { sm.n_final = ~0u; sm.tix_ahead = (uint32_t)kTixAhead; }
+        // the workgroup's first tile number goes to the data waves here, so that they find it at their first look (they
+        // would sleep through the scout's first round otherwise: ~1 us at the start of every launch)
+        bool first_published = false;
+        if (wave == kDataWaves) {
+            const uint32_t k   = uni(first_ticket);
+            const uint32_t cls = blockIdx.x % (uint32_t)kTicketClasses;
+            const uint32_t t   = k * (uint32_t)kTicketClasses + ((cls + k) % (uint32_t)kTicketClasses);
+            if ((uint64_t)k * kTicketClasses < p.num_tiles && (uint64_t)t < p.num_tiles) {
+                first_published = true;
+                if (lane == 0) {
+                    if (t == 0u) st_word(&p.recs()[0].tail, kValid32);          // nothing precedes tile 0: its predecessor's tail is empty
+                    sm.tq[0] = t;
+                    sm.n_tickets = 1u;
+                }
+            }
+        }
         __syncthreads();
         TLX(p, 2, tid == 0);                                         // LDS is set up: the roles part
 #ifdef HVLC_PRIO_YOUNG
@@ -1802,7 +1820,7 @@ k_encode(EncodeParams p)
             // workgroup 0's scout lives about as long as the launch: its lifetime in shader clocks and in 100 MHz ticks
             // tells the clock the GPU held (hvlc_get_clock_info)
             const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-            encode_scout_wave(p, sm, lane, first_ticket);
+            encode_scout_wave(p, sm, lane, first_ticket, first_published);
             if (blockIdx.x == 0 && lane == 0) {
                 uint64_t* const clk = reinterpret_cast<uint64_t*>(ctl + kCtlClock);
                 clk[0] = __builtin_amdgcn_s_memtime() - c0;
