@@ -61,7 +61,7 @@ struct hvlc_ctx {
 namespace {
 
 // the layout of the workspace is the device header's (EncodeParams)
-static_assert(kWsOffBits32 == kTicketClasses * kTicketStride * 4, "ticket counters sit in front of bits32");
+static_assert(kWsOffBits32 >= kTicketClasses * kTicketStride * 4, "ticket counters sit in front of bits32");
 
 #define HVLC_HIP(ctx, call)                                   \
     do {                                                      \

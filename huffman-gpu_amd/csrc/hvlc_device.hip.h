@@ -2093,9 +2093,10 @@ constexpr int kDecTop     = 4;                 // words (x4 symbols) between two
 constexpr int kDecChunk   = 16;                // words per lane between two flushes
 constexpr int kDecRing    = 16;                // ring dwords per lane (+2 mirror slots: slots 16, 17 repeat slots 0, 1)
 constexpr int kDecAhead   = 8;                 // words a ring must hold ahead of the read position at a top-up
+constexpr int kDecIssue   = 12;                // ... below which the next 16 bytes are requested for the top-up after this one
 constexpr int kDecStride  = 17;                // LDS words per lane in the output staging area
 static_assert((31 + (kDecTop * 4 - 4) * kDecBits) / 32 + 2 < kDecAhead, "short codes cannot outrun the ring between two top-ups");
-static_assert(kDecAhead + 3 + 4 <= kDecRing, "a top-up never overwrites words still to be read");
+static_assert(kDecAhead + 3 + 4 <= kDecRing && kDecIssue + 4 <= kDecRing, "a top-up never overwrites words still to be read");
 
 struct alignas(16) DecSmem {
     uint16_t fast[1 << kDecBits];              // (symbol << 8) | length, 0 = a longer code.  The length sits in the LOW byte: a
@@ -2196,25 +2197,37 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
             }
             return ((((uint64_t)w0 << 32) | (uint64_t)w1) << sh) | (((uint64_t)w2 << sh) >> 32);
         };
+        // the ring is topped up ONE STEP AHEAD: the 16 bytes a lane will need are requested here and written into the ring
+        // at the next top-up (`pend`), so the trip to memory is covered by the decoding of four words -- a wave that waits
+        // for its load on the spot waits at almost every top-up, because some lane of its 64 always needs one
+        u32x4 pv = {0u, 0u, 0u, 0u};
+        bool pend = false;
+        auto load16 = [&](uint32_t at) -> u32x4 {
+            const uint64_t wi = wbase + at;
+            u32x4 v;
+            if (wi + 4 <= total_words) v = *(const u32x4*)(bits + wi);
+            else { v.x = dec_word(bits, total_words, wi); v.y = dec_word(bits, total_words, wi + 1);
+                   v.z = dec_word(bits, total_words, wi + 2); v.w = dec_word(bits, total_words, wi + 3); }
+            return v;
+        };
+        auto commit16 = [&](const u32x4& v) {
+            const uint32_t sl = have & (kDecRing - 1);
+            ring[sl][lane] = v.x; ring[sl + 1][lane] = v.y; ring[sl + 2][lane] = v.z; ring[sl + 3][lane] = v.w;
+            if (sl == 0u) { ring[kDecRing][lane] = v.x; ring[kDecRing + 1][lane] = v.y; }       // the mirror slots
+            have += 4;
+        };
         for (int chunk = 0; chunk < kSegWords / kDecChunk; ++chunk) {
 #pragma unroll 1
             for (int top = 0; top < kDecChunk / kDecTop; ++top) {
-                // ---- top up: every lane whose ring holds fewer than kDecAhead words ahead loads its next aligned 16 bytes
-                // (a lane that long codes took far ahead skips the words it will never read)
-                if (have + kDecRing < (pb >> 5)) have = (pb >> 5) & ~3u;
+                // ---- top up.  What was requested at the previous top-up goes into the ring; a lane whose ring will hold
+                // fewer than kDecIssue words ahead requests its next aligned 16 bytes; a lane that even so holds fewer than
+                // kDecAhead (the start of a segment; codes of 9 bits and more on average) gets them on the spot
+                if (have + kDecRing < (pb >> 5)) { have = (pb >> 5) & ~3u; pend = false; }   // (long codes took the lane far ahead: skip what it will never read)
+                if (pend) { commit16(pv); pend = false; }
                 while (__any(have < (pb >> 5) + (uint32_t)kDecAhead)) {
-                    if (have < (pb >> 5) + (uint32_t)kDecAhead) {
-                        const uint64_t wi = wbase + have;
-                        u32x4 v;
-                        if (wi + 4 <= total_words) v = *(const u32x4*)(bits + wi);
-                        else { v.x = dec_word(bits, total_words, wi); v.y = dec_word(bits, total_words, wi + 1);
-                               v.z = dec_word(bits, total_words, wi + 2); v.w = dec_word(bits, total_words, wi + 3); }
-                        const uint32_t sl = have & (kDecRing - 1);
-                        ring[sl][lane] = v.x; ring[sl + 1][lane] = v.y; ring[sl + 2][lane] = v.z; ring[sl + 3][lane] = v.w;
-                        if (sl == 0u) { ring[kDecRing][lane] = v.x; ring[kDecRing + 1][lane] = v.y; }       // the mirror slots
-                        have += 4;
-                    }
+                    if (have < (pb >> 5) + (uint32_t)kDecAhead) commit16(load16(have));
                 }
+                if (have < (pb >> 5) + (uint32_t)kDecIssue) { pv = load16(have); pend = true; }
                 // (same lane, same wave: LDS operations complete in order, no barrier)
 #pragma unroll
                 for (int w = 0; w < kDecTop; ++w) {

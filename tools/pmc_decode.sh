@@ -8,4 +8,4 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_
    --output-format csv -d $OUT/p1 -- $B > $OUT/p1.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM \
    --output-format csv -d $OUT/p2 -- $B > $OUT/p2.log 2>&1 || exit 1
-KERNEL=k_decode python3 tools/pmc_summary.py $OUT
+KERNEL=${KERNEL:-k_decode} python3 tools/pmc_summary.py $OUT
