@@ -174,18 +174,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):     # (at least one untimed step: its bit total sizes the probes and is checked below)
-        step()
+    step()                                   # (set-up, not a warm-up step: its bit total sizes the probes and is checked here)
     fence()
     bits, rc = enc.finish()
     assert rc == 0, hvlc.status_string(rc)
     assert bits == int((local_hist * cl).sum()), "bit total does not match histogram x lengths"
 
     # ---- what the memory system gives this traffic mix with no encoding work ("in the same run").  Here,
-    # between the warm-up and the timed steps: the probes clobber `out`, which every step rewrites, and the GPU goes into
-    # the timed region busy instead of idle (after the set-up's host work its clocks take ~30 ms of work to come back:
-    # the first timed steps of an idle start ran 20 % slower than the last, profiles/r02_kernel_trace.csv)
+    # in FRONT of the warm-up steps: the GPU then goes through the warm-up into the timed region busy instead of idle
+    # (after the set-up's host work its clocks take ~30 ms of work to come back: the first timed steps of an idle start ran
+    # 20 % slower than the last, profiles/r02_kernel_trace.csv), and nothing but the W warm-up steps and one fence lies
+    # between the probes and the timed steps (round 3's first arrangement freed the probes' buffer there: a pause of
+    # milliseconds, and a mean step 1.3-2.5 % above the median)
     probe = None
+    pbuf = None
     if not args.no_probe:
         wpt = max(4, (int(round(1024.0 * bits / n_bytes / 32.0 * 4.0)) + 3) // 4 * 4)   # stream words per 4 KiB of input
         rd_best, _ = enc.probe_bandwidth(d_in, None, 0, 0)
@@ -196,7 +198,7 @@ def main():
                   9: "dwordx4 nt, 15 reader waves (two steps in flight) + a writer wave per CU"}
         mix = {}
         # (the burst and role shapes write a region per wave / workgroup and burst: up to twice the stream plus slack, more
-        # than a tight output buffer holds -- the probes get a buffer of their own, freed before the timed region)
+        # than a tight output buffer holds -- the probes get a buffer of their own, freed behind the timed region)
         pbuf = torch.empty(max(out.numel(), (n_bytes // 4096) * wpt * 2 + (64 << 20), n_words), dtype=torch.int32, device=dev)
         for shape in shapes:
             try:
@@ -204,10 +206,12 @@ def main():
             except hvlc.HvlcError:
                 pass
         copy_ms = enc.probe_bandwidth(d_in, pbuf, 0, 7)[0]
-        del pbuf
-        torch.cuda.empty_cache()
         best_shape = min(mix, key=mix.get)
         probe = (rd_best, mix[best_shape], wpt, shapes[best_shape], {shapes[k]: round(n_bytes * (1.0 + wpt / 1024.0) / v / 1e6, 1) for k, v in mix.items()}, copy_ms)
+
+    # ---- the W warm-up steps, untimed, right in front of the timed region
+    for _ in range(args.warmup):
+        step()
 
     # ---- the timed region: EXACTLY args.steps steps between two fences, nothing else on the stream but ONE HIP event in
     # front and one behind (per-launch events cost 4-13 us per step: 1 % of a 4 GiB step, 12 % of a 256 MiB one,
@@ -224,6 +228,7 @@ def main():
     region_ms = ev_a.elapsed_time(ev_b)
     bits2, rc = enc.finish()
     assert rc == 0 and bits2 == bits
+    del pbuf                                 # (the probes' buffer: kept until here so that nothing pauses the GPU in front of the timed region)
     # ---- an instrumented pass of the same steps right behind it, NOT part of `value`: HIP events around every k_encode
     # launch (hvlc_profile_*) and between the steps, for the median / best figures of SURVEY.md 8(d)
     enc.profile_begin(args.steps)
@@ -357,7 +362,7 @@ def main():
             "measured_mix_ceiling_shape": mix_shape,
             "measured_mix_by_shape": mix_all,
             "measured_copy": round(2.0 * n_bytes / copy_ms / 1e6, 1) if copy_ms else None,
-            "measured_ceiling_note": f"same process, GB/s of bytes read + written, no encoding work, measured between the warm-up and the timed "
+            "measured_ceiling_note": f"same process, GB/s of bytes read + written, no encoding work, measured in front of the warm-up and the timed "
                                      f"steps: read-only dwordx4 nt stream of the input; the same + {wpt * 4} B written per 4 KiB read, the MAXIMUM "
                                      f"over eight shapes (measured_mix_by_shape); a plain 1:1 dwordx4 nt copy of the input (measured_copy; the "
                                      f"guide's figure for a float4 copy is 6290)",
