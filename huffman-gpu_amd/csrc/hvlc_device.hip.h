@@ -1684,16 +1684,17 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
     }
 }
 
-// The persistent, pipelined encoder.  A workgroup = 7 DATA waves + 1 SCOUT wave (two waves per SIMD whatever the
-// placement).  It draws tiles from the ticket counters; every data wave keeps several packed parts in its LDS ring
-// while the scout waits for their tiles' global bit offsets, so HBM latency, the inter-workgroup hand-offs and the
-// LDS bit packing of several tiles overlap inside one wave, on top of the overlap between the waves of a CU.
+// The persistent, pipelined encoder.  A workgroup = kDataWaves (10) DATA waves + 1 SCOUT wave + 1 STORE wave (three
+// waves per SIMD whatever the placement).  It draws tiles from the ticket counters; every data wave keeps several packed
+// parts in its LDS ring while the scout waits for their tiles' global bit offsets and the store wave writes resolved
+// tiles, so HBM latency, the inter-workgroup hand-offs, the LDS bit packing and the stores of several tiles overlap
+// inside a workgroup, on top of the overlap between the two workgroups of a CU.
 #ifndef HVLC_WAVES_PER_EU
 #define HVLC_WAVES_PER_EU 6
 #endif
 // LDS is passed as dynamic shared memory (sizeof(Smem)) so that the register allocator honours the
 // waves-per-SIMD request below instead of the occupancy the static LDS size would imply: 80 VGPRs
-// = 6 waves per SIMD = three 8-wave workgroups per CU.
+// = 6 waves per SIMD = two 12-wave workgroups per CU.
 __global__ void __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(HVLC_WAVES_PER_EU, 8)))
 k_encode(EncodeParams p)
 {
