@@ -1814,9 +1814,10 @@ k_encode(EncodeParams p)
         if (wave >= 8 && wave < kDataWaves) __builtin_amdgcn_s_setprio(2);
         else if (wave >= 4 && wave < kDataWaves) __builtin_amdgcn_s_setprio(1);
 #endif
-#ifdef HVLC_PRIO_SCOUT
+#ifndef HVLC_PRIO_SCOUT
+#define HVLC_PRIO_SCOUT 1        // (the scout's rounds are short and twenty data waves' tiles wait for them: +0.7 % H2.2, +1.4 % H4.0,
+#endif                           //  +0.9 % H1.0 over priority 0, the same at 3: tools/ab.py, round 3; the store wave runs at 3)
         if (wave == kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_SCOUT);
-#endif
         if (wave == kDataWaves) {
             // workgroup 0's scout lives about as long as the launch: its lifetime in shader clocks and in 100 MHz ticks
             // tells the clock the GPU held (hvlc_get_clock_info)
