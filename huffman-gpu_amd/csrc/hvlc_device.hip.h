@@ -487,8 +487,11 @@ __device__ __forceinline__ void put_row_pairs_mem(uint32_t* st, uint32_t q, cons
 // A workgroup's n-th tile uses slot n % kSlots; a slot is reused only after the store wave has freed the slot's
 // previous tile, so the fastest data wave runs at most kSlots-1 tiles ahead of the store wave.
 // ---------------------------------------------------------------------------------------------
-constexpr int      kSlots   = 8;
-constexpr int      kTq      = 16;                          // queue of drawn tile numbers: workgroup-local tile n at [n % kTq]
+#ifndef HVLC_SLOTS
+#define HVLC_SLOTS 8
+#endif
+constexpr int      kSlots   = HVLC_SLOTS;
+constexpr int      kTq      = HVLC_SLOTS <= 8 ? 16 : 32;                         // queue of drawn tile numbers: workgroup-local tile n at [n % kTq]
 #ifndef HVLC_TICKETS_AHEAD
 #define HVLC_TICKETS_AHEAD 2
 #endif
@@ -1831,7 +1834,10 @@ k_encode(EncodeParams p)
         }
         else if (wave == kDataWaves + 1) {
 #ifndef HVLC_NO_STORE_PRIO
-            __builtin_amdgcn_s_setprio(3);       // one short, serial instruction stream that ten data waves wait for
+#ifndef HVLC_PRIO_STORE
+#define HVLC_PRIO_STORE 3
+#endif
+            __builtin_amdgcn_s_setprio(HVLC_PRIO_STORE);       // one short, serial instruction stream that ten data waves wait for
 #endif
             encode_store_wave(p, sm, lane);
         }
