@@ -490,6 +490,17 @@ __device__ __forceinline__ void put_row_pairs_mem(uint32_t* st, uint32_t q, cons
 #ifndef HVLC_SLOTS
 #define HVLC_SLOTS 8
 #endif
+// Issue priorities (s_setprio; tools/ab.py, round 3).  The store wave runs at 3 (one short serial instruction stream that ten
+// data waves wait for: +12 %); the scout at 1 (its rounds are short and twenty data waves' tiles wait for them: +0.6 % H2.2,
+// +1.5 % H4.0, +1.1 % H1.0 over 0, the same at 2 or 3); a data wave at 1 while it works on the workgroup's OLDEST
+// unpublished tile and at 0 when it is ahead (a tile is published by its slowest wave, and which wave that is is decided
+// by who wins the SIMD's issue arbitration -- the older waves, left alone: +2.1-2.6 % H2.2, 0...+3 % H1.0), but only
+// while the rings hold more than three parts (at H4.0 they do not, the waves wait for ring words and the priority
+// costs 2-4 %).  Priority 0 again once the wave has arrived (-1 %), 2 for a wave that finds half of the others arrived
+// already (+-0), 2 or 3 for a scout on leader's duty (+-0): measured, not taken.
+#ifndef HVLC_PRIO_SCOUT
+#define HVLC_PRIO_SCOUT 1
+#endif
 constexpr int      kSlots   = HVLC_SLOTS;
 constexpr int      kTq      = HVLC_SLOTS <= 8 ? 16 : 32;                         // queue of drawn tile numbers: workgroup-local tile n at [n % kTq]
 #ifndef HVLC_TICKETS_AHEAD
@@ -915,10 +926,27 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         const uint32_t cur  = uni(sm.tq[n_packed % kTq]);
         const uint32_t slot = n_packed % kSlots;
         const bool full = cur != last_tile || part_is_full(p, cur, wave);   // (only the part the input ends in, and the empty ones behind it, are not)
+#ifndef HVLC_PRIO_ADAPT
+#define HVLC_PRIO_ADAPT 1
+#endif
+#if HVLC_PRIO_ADAPT
+#ifndef HVLC_PRIO_ADAPT_MIN_AHEAD
+#define HVLC_PRIO_ADAPT_MIN_AHEAD 2u
+#endif
+        // issue priority goes to the waves that work on the workgroup's OLDEST unpublished tile (see HVLC_PRIO_SCOUT above)
+        if (n_packed <= lds_rlx(&sm.n_bits_pub) && lds_rlx(&sm.tix_ahead) >= HVLC_PRIO_ADAPT_MIN_AHEAD) {
+            __builtin_amdgcn_s_setprio(HVLC_PRIO_ADAPT);
+        }
+        else __builtin_amdgcn_s_setprio(0);
+#endif
 
         // ---- 1: lookups, concatenation, scan (registers only)
 #ifdef HVLC_EXPERIMENT
         if (n_packed == 0u && wave == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TLX(p, 4, lane == 0); }   // the first tile's words are here
+#ifdef HVLC_WS_LOADWAIT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (wave_stats: how long a data wave waits for its input, by itself)
+        WS_LAP(kWsWaitDrain);
+#endif
 #endif
         uint64_t acc[kRows];
         uint32_t tot[kRows], incl[kRows], rowbase[kRows];
@@ -1641,6 +1669,7 @@ __device__ __forceinline__ void encode_scout_wave(const EncodeParams& p, Smem& s
             TL(p, (uint64_t)d.g * kGroupTiles + d.n - 1u, 3, lane == 0);
             d.active = false;
             progress = true;
+
         }
 
         // (4) newly published tiles: start polling their records; the last tile of a group starts that group's duty
@@ -1817,9 +1846,6 @@ k_encode(EncodeParams p)
         if (wave >= 8 && wave < kDataWaves) __builtin_amdgcn_s_setprio(2);
         else if (wave >= 4 && wave < kDataWaves) __builtin_amdgcn_s_setprio(1);
 #endif
-#ifndef HVLC_PRIO_SCOUT
-#define HVLC_PRIO_SCOUT 1        // (the scout's rounds are short and twenty data waves' tiles wait for them: +0.7 % H2.2, +1.4 % H4.0,
-#endif                           //  +0.9 % H1.0 over priority 0, the same at 3: tools/ab.py, round 3; the store wave runs at 3)
         if (wave == kDataWaves) __builtin_amdgcn_s_setprio(HVLC_PRIO_SCOUT);
         if (wave == kDataWaves) {
             // workgroup 0's scout lives about as long as the launch: its lifetime in shader clocks and in 100 MHz ticks

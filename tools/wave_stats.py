@@ -7,7 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "huffman-gpu_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("HVLC_LIB", os.path.join(ROOT, "huffman-gpu_amd", "libhvlc_exp.so"))
-NAMES = ["encode(+load wait)", "prefetch issue | STORE", "arrive", "zero+pack", "wait ticket | RESOLVE", "-", "wait slot", "wait ring",
+NAMES = ["encode(+load wait)", "prefetch issue | STORE", "arrive", "zero+pack", "wait ticket | RESOLVE", "load wait (HVLC_WS_LOADWAIT)", "wait slot", "wait ring",
          "slow path", "wait tail", "total", "tiles", "nwaits"]
 
 def main():
