@@ -497,7 +497,8 @@ __device__ __forceinline__ void put_row_pairs_mem(uint32_t* st, uint32_t q, cons
 // by who wins the SIMD's issue arbitration -- the older waves, left alone: +2.1-2.6 % H2.2, 0...+3 % H1.0), but only
 // while the rings hold more than three parts (at H4.0 they do not, the waves wait for ring words and the priority
 // costs 2-4 %).  Priority 0 again once the wave has arrived (-1 %), 2 for a wave that finds half of the others arrived
-// already (+-0), 2 or 3 for a scout on leader's duty (+-0): measured, not taken.
+// already (+-0), 2 or 3 for a scout on leader's duty (+-0), three levels by the age of the wave's tile (2 / 1 / 0: -1 %, +-0 with
+// the scout at 2): measured, not taken.
 #ifndef HVLC_PRIO_SCOUT
 #define HVLC_PRIO_SCOUT 1
 #endif
@@ -1047,7 +1048,10 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
                 // waits for it.  Measured (tools/ab.py): 1 tile ahead is best at 3 parts per ring (4 bits per symbol: +6 %
                 // over 2), 3 at 9 parts (1.3 bits per symbol: +3 %), 2 in between.
                 const uint32_t parts = kWaveRing / ring_need(Ttile / (uint32_t)kDataWaves);
-                sm.tix_ahead = parts <= 3u ? 1u : parts >= 8u ? 3u : 2u;
+#ifndef HVLC_AHEAD3_PARTS
+#define HVLC_AHEAD3_PARTS 8u
+#endif
+                sm.tix_ahead = parts <= 3u ? 1u : parts >= HVLC_AHEAD3_PARTS ? 3u : 2u;
 #endif
                 sm.ts[slot].arrive = 0u;
                 (void)__hip_atomic_fetch_max(&sm.n_bits_pub, n_packed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
