@@ -195,7 +195,9 @@ def main():
         # steps; readers and a writer wave per workgroup): the ceiling is the BEST of them -- round 2 took the per-step shapes only and the encoder beat its "ceiling"
         shapes = {1: "dword", 2: "dwordx4", 3: "dword nt", 4: "dwordx4 nt", 5: "dwordx4 nt, bursts of 10 steps", 6: "dwordx4 nt, bursts of 32 steps",
                   8: "dwordx4 nt, 15 reader waves (one step in flight) + a writer wave per CU",
-                  9: "dwordx4 nt, 15 reader waves (two steps in flight) + a writer wave per CU"}
+                  9: "dwordx4 nt, 15 reader waves (two steps in flight) + a writer wave per CU",
+                  10: "dwordx4 nt, 15 reader waves (three steps in flight) + a writer wave per CU",
+                  11: "dwordx4 nt, 2 x (10 reader waves, one step in flight, + a writer wave) per CU"}
         mix = {}
         # (the burst and role shapes write a region per wave / workgroup and burst: up to twice the stream plus slack, more
         # than a tight output buffer holds -- the probes get a buffer of their own, freed behind the timed region)
@@ -206,8 +208,6 @@ def main():
             except hvlc.HvlcError:
                 pass
         copy_ms = enc.probe_bandwidth(d_in, pbuf, 0, 7)[0]
-        best_shape = min(mix, key=mix.get)
-        probe = (rd_best, mix[best_shape], wpt, shapes[best_shape], {shapes[k]: round(n_bytes * (1.0 + wpt / 1024.0) / v / 1e6, 1) for k, v in mix.items()}, copy_ms)
 
     # ---- the W warm-up steps, untimed, right in front of the timed region
     for _ in range(args.warmup):
@@ -228,6 +228,15 @@ def main():
     region_ms = ev_a.elapsed_time(ev_b)
     bits2, rc = enc.finish()
     assert rc == 0 and bits2 == bits
+    if not args.no_probe:
+        # the three best mix shapes, the copy and the read-only stream once more BEHIND the timed region (the GPU's state
+        # drifts over a run: whichever of the two measurements is the better one counts -- a ceiling is a maximum)
+        for shape in sorted(mix, key=mix.get)[:3]:
+            mix[shape] = min(mix[shape], enc.probe_bandwidth(d_in, pbuf, wpt, shape)[0])
+        copy_ms = min(copy_ms, enc.probe_bandwidth(d_in, pbuf, 0, 7)[0])
+        rd_best = min(rd_best, enc.probe_bandwidth(d_in, None, 0, 0)[0])
+        best_shape = min(mix, key=mix.get)
+        probe = (rd_best, mix[best_shape], wpt, shapes[best_shape], {shapes[k]: round(n_bytes * (1.0 + wpt / 1024.0) / v / 1e6, 1) for k, v in mix.items()}, copy_ms)
     del pbuf                                 # (the probes' buffer: kept until here so that nothing pauses the GPU in front of the timed region)
     # ---- an instrumented pass of the same steps right behind it, NOT part of `value`: HIP events around every k_encode
     # launch (hvlc_profile_*) and between the steps, for the median / best figures of SURVEY.md 8(d)
@@ -362,9 +371,9 @@ def main():
             "measured_mix_ceiling_shape": mix_shape,
             "measured_mix_by_shape": mix_all,
             "measured_copy": round(2.0 * n_bytes / copy_ms / 1e6, 1) if copy_ms else None,
-            "measured_ceiling_note": f"same process, GB/s of bytes read + written, no encoding work, measured in front of the warm-up and the timed "
+            "measured_ceiling_note": f"same process, GB/s of bytes read + written, no encoding work, measured in front of the warm-up and, the best shapes once more, behind the timed "
                                      f"steps: read-only dwordx4 nt stream of the input; the same + {wpt * 4} B written per 4 KiB read, the MAXIMUM "
-                                     f"over eight shapes (measured_mix_by_shape); a plain 1:1 dwordx4 nt copy of the input (measured_copy; the "
+                                     f"over ten shapes (measured_mix_by_shape); a plain 1:1 dwordx4 nt copy of the input (measured_copy; the "
                                      f"guide's figure for a float4 copy is 6290)",
             "frac_of_measured_mix": round(achieved / (mix_total / mix_best / 1e6), 4)})
 

@@ -655,7 +655,7 @@ int hvlc_probe_bandwidth(hvlc_ctx* c, const void* d_in, uint64_t n_bytes, void* 
                          uint32_t out_words_per_4k, int store_shape, int iters, float* ms_best, float* ms_median)
 {
     if (!c || !d_in || !ms_best || n_bytes < 4096 || ((uintptr_t)d_in & 15u) || iters < 1 || iters > 64 ||
-        store_shape < 0 || store_shape > 9)
+        store_shape < 0 || store_shape > 11)
         return HVLC_ERR_ARG;
     const uint64_t tiles = n_bytes / 4096;
     const bool vec4 = store_shape == 2 || store_shape >= 4;      // (dwordx4 stores: whole 16-byte pieces)
@@ -669,8 +669,9 @@ int hvlc_probe_bandwidth(hvlc_ctx* c, const void* d_in, uint64_t n_bytes, void* 
         uint64_t need = burst == 1u ? tiles * (uint64_t)out_words_per_4k * 4u
                                     : ((tiles / waves + burst) / burst + 1u) * waves * (uint64_t)out_words_per_4k * burst * 4u;
         if (store_shape >= 8) {
-            const uint64_t per_round = (uint64_t)c->cus * kProbeReaders;
-            need = ((tiles / per_round + kProbeRounds) / kProbeRounds + 1u) * (uint64_t)c->cus * kProbeReaders * kProbeRounds * (uint64_t)out_words_per_4k * 4u;
+            const uint64_t wgs = (uint64_t)c->cus * (store_shape == 11 ? 2u : 1u), readers = store_shape == 11 ? kProbeReaders2 : kProbeReaders;
+            const uint64_t per_round = wgs * readers;
+            need = ((tiles / per_round + kProbeRounds) / kProbeRounds + 1u) * per_round * kProbeRounds * (uint64_t)out_words_per_4k * 4u;
         }
         if (!d_out || ((uintptr_t)d_out & 15u) || out_words_per_4k == 0 || (vec4 && (out_words_per_4k & 3u)) || need > out_bytes)
             return HVLC_ERR_ARG;
@@ -695,8 +696,10 @@ int hvlc_probe_bandwidth(hvlc_ctx* c, const void* d_in, uint64_t n_bytes, void* 
                 case 4:  e = launch(k_probe_rw<4>, grid, block, 0, nullptr, in, tiles, out, out_words_per_4k, burst, sink); break;
                 case 5: case 6:
                          e = launch(k_probe_rw<5>, grid, block, 0, nullptr, in, tiles, out, out_words_per_4k, burst, sink); break;
-                case 8:  e = launch(k_probe_roles<1>, dim3((unsigned)c->cus), dim3(64 * (kProbeReaders + 1)), 0, nullptr, in, tiles, out, out_words_per_4k, sink); break;
-                case 9:  e = launch(k_probe_roles<2>, dim3((unsigned)c->cus), dim3(64 * (kProbeReaders + 1)), 0, nullptr, in, tiles, out, out_words_per_4k, sink); break;
+                case 8:  e = launch(k_probe_roles<1>, dim3((unsigned)c->cus), dim3(64 * (kProbeReaders + 1)), 0, nullptr, in, tiles, out, out_words_per_4k, sink, (int)kProbeReaders); break;
+                case 9:  e = launch(k_probe_roles<2>, dim3((unsigned)c->cus), dim3(64 * (kProbeReaders + 1)), 0, nullptr, in, tiles, out, out_words_per_4k, sink, (int)kProbeReaders); break;
+                case 10: e = launch(k_probe_roles<3>, dim3((unsigned)c->cus), dim3(64 * (kProbeReaders + 1)), 0, nullptr, in, tiles, out, out_words_per_4k, sink, (int)kProbeReaders); break;
+                case 11: e = launch(k_probe_roles<1>, dim3((unsigned)c->cus * 2u), dim3(64 * (kProbeReaders2 + 1)), 0, nullptr, in, tiles, out, out_words_per_4k, sink, (int)kProbeReaders2); break;
                 default: e = launch(k_probe_copy, dim3((unsigned)c->cus * 4u), block, 0, nullptr, in, (uint4*)d_out, tiles * 256u); break;
             }
         }

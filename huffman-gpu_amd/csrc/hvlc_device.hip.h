@@ -2347,10 +2347,12 @@ __global__ void __launch_bounds__(kDecThreads) k_decode(const uint32_t* __restri
 //               the encoder's store wave does; 32) as one contiguous stretch every `burst`-th step
 //         8:    (k_probe_roles) the encoder's DIVISION OF LABOUR, in the geometry the memory system likes best (tools/
 //               ubench_mem.hip, profiles/r03_ubench_roles.txt): ONE workgroup of 15 reader waves + 1 writer wave per CU; a
-//               reader only reads (4 KiB steps, one -- shape 8 -- or two -- shape 9 -- in flight), the writer only writes -- the output of four
+//               reader only reads (4 KiB steps, one -- shape 8 --, two -- shape 9 -- or three -- shape 10 -- in flight), the writer only writes -- the output of four
 //               rounds of its workgroup as one stretch (dwordx4, non-temporal), paced by the readers through a counter in
 //               LDS.  No wave has loads queued behind its own stores (vector memory operations of a wave return in order),
 //               and few waves keep the queues short: 6.2 TB/s of bytes moved where the per-step shapes reach 5.1-5.4
+//         11:   the same in the encoder's OWN geometry: two workgroups of 10 reader waves (one step in flight) + 1 writer wave
+//               per CU -- the better shape on some boxes of the pool at low write shares (tools/ubench_mem.hip mode 4)
 // k_probe_copy: a plain 1:1 copy (dwordx4 non-temporal loads and stores), the known-good reference of a read/write mix.
 // ---------------------------------------------------------------------------------------------
 template <int STORE>
@@ -2400,12 +2402,12 @@ __global__ void __launch_bounds__(kThreads) k_probe_rw(const uint4* __restrict__
 }
 
 constexpr int kProbeReaders = 15, kProbeRounds = 4;        // k_probe_roles: reader waves per workgroup (+1 writer), rounds per writer burst
+constexpr int kProbeReaders2 = 10;                          // ... in the encoder's own geometry (shape 11): two workgroups of 10 readers + 1 writer per CU
 template <int DEPTH>                                        // 4 KiB steps a reader keeps in flight
 __global__ void __launch_bounds__(64 * (kProbeReaders + 1)) k_probe_roles(const uint4* __restrict__ in, uint64_t tiles4k,
-                                                                          uint32_t* __restrict__ out, uint32_t wpt, uint32_t* sink)
+                                                                          uint32_t* __restrict__ out, uint32_t wpt, uint32_t* sink, int R)
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int R = kProbeReaders;
     constexpr uint32_t rounds = kProbeRounds;
     __shared__ uint32_t steps_read;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

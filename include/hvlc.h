@@ -159,9 +159,10 @@ int hvlc_profile_collect(hvlc_ctx* ctx, float* ms, int* count);
  * stores, 5 / 6 = dwordx4 non-temporal stores in bursts: a wave writes the output of 10 steps (a tile's worth: the
  * shape of the encoder's store wave) / of 32 steps as one contiguous stretch (d_out must hold a region per wave and
  * burst: about twice the stream), 7 = a plain 1:1 copy of the input (out_bytes >= n_bytes; out_words_per_4k
- * ignored): the known-good reference of a read/write mix, 8 / 9 = the encoder's division of labour in the
+ * ignored): the known-good reference of a read/write mix, 8 / 9 / 10 = the encoder's division of labour in the
  * geometry the memory system likes best: one workgroup of 15 reader waves and a writer wave per compute unit, a
- * reader with one / two 4 KiB steps in flight, the writer storing four rounds' output as one stretch (no wave has loads queued behind its own stores; d_out: a region
+ * reader with one / two / three 4 KiB steps in flight, the writer storing four rounds' output as one stretch, 11 = the same in the encoder's own geometry (two workgroups of 10
+ * readers with one step in flight and a writer per compute unit) (no wave has loads queued behind its own stores; d_out: a region
  * per workgroup and burst, about the stream's size plus a burst per workgroup).  The ceiling of a
  * workload's mix is the BEST of the shapes.
  * Synchronous on the default stream; runs `iters` launches and returns the best and the median duration in ms. */

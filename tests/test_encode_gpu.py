@@ -556,7 +556,7 @@ def test_probe_bandwidth_shapes_and_argument_checks(enc):
         assert bool((out[words:] == -1).all()) and not bool((out[:words] == -1).all())
     # bursts (the store wave's shape: a wave writes ten or 32 steps' output as one stretch) and the plain 1:1 copy
     big = torch.full((160 << 20,), -1, dtype=torch.int32, device="cuda")        # (a region per wave and burst: 604 MB at 32 steps)
-    for shape in (5, 6, 8, 9):
+    for shape in (5, 6, 8, 9, 10, 11):
         best, med = enc.probe_bandwidth(d_in, big, wpt, shape)
         assert 0 < best <= med and int((big != -1).sum()) == words       # every step's words, each exactly once
         big.fill_(-1)
@@ -572,7 +572,7 @@ def test_probe_bandwidth_shapes_and_argument_checks(enc):
     with pytest.raises(RuntimeError):
         enc.probe_bandwidth(d_in, torch.empty(words, dtype=torch.int32, device="cuda"), wpt, 7)   # copy: as large as the input
     with pytest.raises(RuntimeError):
-        enc.probe_bandwidth(d_in, torch.empty(words, dtype=torch.int32, device="cuda"), wpt, 10)  # no such shape
+        enc.probe_bandwidth(d_in, torch.empty(words, dtype=torch.int32, device="cuda"), wpt, 12)  # no such shape
 
 
 @pytest.mark.parametrize("world", [2, 5])

@@ -173,7 +173,7 @@ static void mix(const Ctx& c, const char* name, int bpc, uint32_t wpt, uint32_t 
 // writer only writes -- every `rounds` rounds the output of its workgroup's R * rounds steps as one stretch.
 template <int DEPTH>
 __global__ void __launch_bounds__(1024) k_roles(const u32x4* __restrict__ in, uint64_t steps, uint32_t* __restrict__ out, uint32_t wpt,
-                                               int R, uint32_t rounds, uint32_t* sink)
+                                               int R, uint32_t rounds, uint32_t* sink, int work = 0)
 {
     __shared__ uint32_t steps_read;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(1024) k_roles(const u32x4* __restrict__ in, ui
                 const uint64_t td = t + (uint64_t)d * nr;
                 if (td < steps) {
                     acc += r[d][0].x ^ r[d][1].y ^ r[d][2].z ^ r[d][3].w;
+                    for (int w = 0; w < work; ++w) acc = acc * 2654435761u + (uint32_t)w;      // (mode 4: a reader that also computes, like an encoder's data wave)
                     if (lane == 0) __hip_atomic_fetch_add(&steps_read, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     const uint64_t tn = td + (uint64_t)DEPTH * nr;
                     if (tn < steps) { const u32x4* q = in + tn * 256u + lane;
@@ -220,14 +221,15 @@ __global__ void __launch_bounds__(1024) k_roles(const u32x4* __restrict__ in, ui
     }
 }
 template <int DEPTH>
-static void roles(const Ctx& c, int wgs_per_cu, int R, uint32_t rounds, uint32_t wpt)
+static void roles(const Ctx& c, int wgs_per_cu, int R, uint32_t rounds, uint32_t wpt, int work = 0)
 {
     const uint64_t steps = c.bytes / 4096;
     float med;
     const float best = time_best([&] {
-        hipLaunchKernelGGL((k_roles<DEPTH>), dim3(256 * wgs_per_cu), dim3(64 * (R + 1)), 0, 0, c.in, steps, c.out, wpt, R, rounds, c.sink);
+        hipLaunchKernelGGL((k_roles<DEPTH>), dim3(256 * wgs_per_cu), dim3(64 * (R + 1)), 0, 0, c.in, steps, c.out, wpt, R, rounds, c.sink, work);
     }, &med);
     const double wr = (double)wpt * 4.0 / 4096.0;
+    if (work) printf("work %4d: ", work);
     printf("roles %2d readers + 1 writer x %d per CU, d%d, writer bursts of %2u rounds (%5.1f KiB), wpt %3u: %.3f ms (med %.3f)  input %5.0f GB/s  total %5.0f GB/s\n",
            R, wgs_per_cu, DEPTH, rounds, R * rounds * wpt * 4 / 1024.0, wpt, best, med, c.bytes / best / 1e6, c.bytes * (1 + wr) / best / 1e6);
     fflush(stdout);
@@ -254,6 +256,12 @@ int main(int argc, char** argv)
                 roles<2>(c, wgs, R, rounds, wpt);
             }
             roles<2>(c, 4, 3, 1, wpt); roles<2>(c, 4, 3, 4, wpt); roles<2>(c, 4, 7, 1, wpt); roles<1>(c, 4, 7, 1, wpt);
+        }
+        return 0;
+    }
+    if (argc > 2 && atoi(argv[2]) == 4) {                         // readers that also compute (`work` multiply-adds per step)
+        for (uint32_t wpt : {172u, 288u}) for (int work : {0, 150, 300, 600}) {
+            roles<2>(c, 1, 15, 4, wpt, work); roles<1>(c, 2, 10, 4, wpt, work); roles<2>(c, 2, 10, 4, wpt, work); roles<1>(c, 2, 11, 4, wpt, work);
         }
         return 0;
     }
