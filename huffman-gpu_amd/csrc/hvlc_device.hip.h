@@ -1008,7 +1008,8 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         TLX(p, 5, wave == 0 && lane == 0 && n_packed == 0u);           // the first part is encoded and scanned
         // ---- 2: the next tile's loads.  (Issued EARLIER -- row by row between the lookups, each row into the registers its
         // lookups had just vacated, when the tile's number was already there -- they made the encoder 7-15 % slower:
-        // tools/ab.py, round 3.  More requests in flight lengthen the queues of a memory system that is busy already.)
+        // tools/ab.py, round 3.  More requests in flight lengthen the queues of a memory system that is busy already.  Issued
+        // LATER, behind the arrival: -0.6 % H2.2, -1.3 % H1.0.)
         (void)try_load();
         WS_LAP(kWsStore);
 

@@ -127,7 +127,10 @@ int hvlc_segment_bits(hvlc_ctx* ctx, const uint32_t* d_in, uint64_t num_words,
  * preallocBlockSums + prescanArray + deallocBlockSums (main_test_cu.cu:160-168)
  * with a single-launch wavefront-hierarchical scan.  Asynchronous like hvlc_encode:
  * a look-back that gives up (bounded wait) is reported by hvlc_finish as
- * HVLC_ERR_TIMEOUT. */
+ * HVLC_ERR_TIMEOUT.  Unlike hvlc_encode the scan numbers its tiles statically: its
+ * grid (what the occupancy query reports as resident, at most four workgroups of
+ * 256 threads per compute unit) must be resident at once, i.e. the device should
+ * not be shared with a long-running kernel while it runs. */
 int hvlc_exclusive_scan(hvlc_ctx* ctx, const uint32_t* d_counts, uint64_t n,
                         uint64_t* d_offsets, uint64_t* d_total, void* stream);
 
