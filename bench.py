@@ -394,7 +394,7 @@ def main():
                        "bytes_per_gpu": n_bytes, "segments_per_gpu": S, "out_bits_per_gpu": bits,
                        "bits_per_symbol": round(bits / n_bytes, 4),
                        "parallelism": f"shard{world}" if world > 1 else "single",
-                       "grid_blocks": info["grid_blocks"], "blocks_per_cu": info["blocks_per_cu"]},
+                       "grid_blocks": info["grid_blocks"], "blocks_per_cu": info["blocks_per_cu"], "data_waves_per_workgroup": info["data_waves"]},
             "hbm_frac_of_peak_input_bytes": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": roofline, "cpu_baseline": cpu,
         }

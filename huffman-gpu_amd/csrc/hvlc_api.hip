@@ -15,6 +15,20 @@
 #endif
 #include "../../include/hvlc.h"
 #include "hvlc_device.hip.h"
+// the second geometry of the encoder (eight data waves, rings of 2188 words): see the header's first lines.  A build with
+// -DHVLC_DATA_WAVES=... (tools/) has one geometry only.
+#if HVLC_DATA_WAVES == 10 && !defined(HVLC_SINGLE_GEOMETRY) && !defined(HVLC_EXPERIMENT)   // (experiment builds: the tools' debug buffers are sized for one geometry)
+#define HVLC_TWO_GEOMETRIES 1
+#undef HVLC_NS
+#undef HVLC_DATA_WAVES
+#undef HVLC_WAVE_RING_WORDS
+#define HVLC_NS hvlc8
+#define HVLC_DATA_WAVES 8
+#define HVLC_WAVE_RING_WORDS 2188
+#include "hvlc_device.hip.h"
+#undef HVLC_NS
+#define HVLC_NS hvlc
+#endif
 
 #include <hip/hip_runtime.h>
 
@@ -37,6 +51,11 @@ struct hvlc_ctx {
     int       device        = 0;
     int       cus           = 0;
     int       blocks_per_cu = 0;
+    int       blocks_per_cu8 = 0;        // ... of the eight-data-wave geometry
+    int       geometry      = 0;         // 0: ten data waves per workgroup, 1: eight (chosen per call, see hvlc_finish)
+    int       geometry_forced = -1;      // HVLC_GEOMETRY=10|8 (read once by hvlc_create): tests and tools
+    int       last_geometry = 0;
+    uint64_t  last_words    = 0;         // input words of the last encode launched
     int       last_hip      = 0;
     int       last_grid     = 0;
     uint8_t*  ws            = nullptr;   // [control block 64 B][granule area, half 0][half 1]  (EncodeParams, hvlc_device.hip.h)
@@ -243,9 +262,20 @@ int hvlc_create(hvlc_ctx** out, int device, uint64_t max_words)
     if (e != hipSuccess) { delete c; return HVLC_ERR_HIP; }
     c->cus = prop.multiProcessorCount;
     c->blocks_per_cu = pick_blocks_per_cu(c, k_encode, kEncThreads, sizeof(Smem), env_int("HVLC_MAX_BLOCKS_PER_CU", 8));
+#ifdef HVLC_TWO_GEOMETRIES
+    c->blocks_per_cu8 = pick_blocks_per_cu(c, hvlc8::k_encode, hvlc8::kEncThreads, sizeof(hvlc8::Smem), env_int("HVLC_MAX_BLOCKS_PER_CU", 8));
+    {
+        const int gf = env_int("HVLC_GEOMETRY", 0);           // 10 or 8: fixes the geometry (tests, tools); anything else: by density
+        c->geometry_forced = gf == 8 ? 1 : gf == 10 ? 0 : -1;
+    }
+#endif
     const int to_ms = env_int("HVLC_TIMEOUT_MS", 2000);
     c->timeout_ticks = (uint64_t)(to_ms > 0 ? to_ms : 2000) * 100000ull;
+#ifdef HVLC_TWO_GEOMETRIES
+    int rc = ensure_workspace(c, (max_words + hvlc8::kTileWords - 1) / hvlc8::kTileWords);     // (the smaller tiles: more of them)
+#else
     int rc = ensure_workspace(c, (max_words + kTileWords - 1) / kTileWords);
+#endif
     if (rc == HVLC_OK && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocDefault) != hipSuccess) rc = HVLC_ERR_NOMEM;
     if (rc != HVLC_OK) { if (c->ws) (void)hipFree(c->ws); delete c; return rc; }
     *out = c;
@@ -274,6 +304,15 @@ int hvlc_get_launch_info(hvlc_ctx* c, int* grid_blocks, int* blocks_per_cu, int*
     return HVLC_OK;
 }
 
+int hvlc_get_geometry(hvlc_ctx* c, int* data_waves_last, int* data_waves_next)
+{
+    if (!c) return HVLC_ERR_ARG;
+    const int next = c->geometry_forced >= 0 ? c->geometry_forced : c->geometry;
+    if (data_waves_last) *data_waves_last = c->last_geometry ? 8 : 10;
+    if (data_waves_next) *data_waves_next = next ? 8 : 10;
+    return HVLC_OK;
+}
+
 int hvlc_last_hip_error(hvlc_ctx* c) { return c ? c->last_hip : 0; }
 
 int hvlc_get_clock_info(hvlc_ctx* c, uint64_t* shader_clocks, uint64_t* realtime_ticks)
@@ -286,23 +325,38 @@ int hvlc_get_clock_info(hvlc_ctx* c, uint64_t* shader_clocks, uint64_t* realtime
     return HVLC_OK;
 }
 
-int hvlc_encode(hvlc_ctx* c,
-                const uint32_t* d_in, uint64_t num_words,
-                const uint32_t* d_codewords, const uint32_t* d_codewordlens,
-                uint32_t* d_out_bits, uint64_t out_capacity_words,
-                uint64_t* d_out_offsets, uint64_t* d_total_bits,
-                void* stream)
+}  // extern "C" (templates next)
+
+// The two geometries of the encoder (hvlc_device.hip.h is compiled twice): what hvlc_encode needs of either.
+struct Geo10 {
+    using Params = hvlc::EncodeParams;
+    static constexpr uint32_t tile_words = hvlc::kTileWords;
+    static constexpr int threads = hvlc::kEncThreads;
+    static constexpr size_t smem = sizeof(hvlc::Smem);
+    static const void* kernel() { return (const void*)hvlc::k_encode; }
+};
+#ifdef HVLC_TWO_GEOMETRIES
+struct Geo8 {
+    using Params = hvlc8::EncodeParams;
+    static constexpr uint32_t tile_words = hvlc8::kTileWords;
+    static constexpr int threads = hvlc8::kEncThreads;
+    static constexpr size_t smem = sizeof(hvlc8::Smem);
+    static const void* kernel() { return (const void*)hvlc8::k_encode; }
+};
+static_assert(sizeof(hvlc8::EncodeParams) == sizeof(hvlc::EncodeParams) && hvlc8::kTileWords < hvlc::kTileWords, "same parameter block, smaller tiles");
+#endif
+
+template <class G>
+static int encode_with(hvlc_ctx* c, int blocks_per_cu,
+                       const uint32_t* d_in, uint64_t num_words,
+                       const uint32_t* d_codewords, const uint32_t* d_codewordlens,
+                       uint32_t* d_out_bits, uint64_t out_capacity_words,
+                       uint64_t* d_out_offsets, uint64_t* d_total_bits, hipStream_t s)
 {
-    if (!c || !d_codewords || !d_codewordlens || !d_out_bits) return HVLC_ERR_ARG;
-    if (num_words && !d_in) return HVLC_ERR_ARG;
-    if (((uintptr_t)d_in & 15u) || ((uintptr_t)d_out_bits & 3u) || ((uintptr_t)d_out_offsets & 7u) ||
-        ((uintptr_t)d_total_bits & 7u))
-        return HVLC_ERR_ARG;
-    if (out_capacity_words < 1) return HVLC_ERR_ARG;
     // every argument and limit is checked before anything is allocated or launched
-    const uint64_t tiles = (num_words + kTileWords - 1) / kTileWords;
+    const uint64_t tiles = (num_words + G::tile_words - 1) / G::tile_words;
     if (tiles > 0x0ffffff0ull) return HVLC_ERR_ARG;          // 28-bit tile numbers (32-bit record offsets): 7 TiB per call
-    uint64_t grid = (uint64_t)c->cus * (uint64_t)c->blocks_per_cu;
+    uint64_t grid = (uint64_t)c->cus * (uint64_t)blocks_per_cu;
     if (c->hook_force_grid > 0) grid = (uint64_t)c->hook_force_grid;
     if (grid > tiles) grid = tiles;
     // every ticket class (block index % kTicketClasses) needs a running workgroup to draw its tiles, and a workgroup
@@ -310,7 +364,6 @@ int hvlc_encode(hvlc_ctx* c,
     // workgroups cannot encode more than one tile per workgroup
     if (grid < tiles && grid < (uint64_t)kTicketClasses) return HVLC_ERR_ARG;
     HVLC_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = (hipStream_t)stream;
     int rc = ensure_workspace(c, tiles);
     if (rc != HVLC_OK) return rc;
 
@@ -321,7 +374,7 @@ int hvlc_encode(hvlc_ctx* c,
         return HVLC_OK;
     }
     const Layout l = layout_for(tiles);
-    EncodeParams p;
+    typename G::Params p;
     memset(&p, 0, sizeof(p));
     p.in = (const uint4*)d_in;  p.num_words = num_words;  p.num_tiles = tiles;
     p.num_segs = hvlc_num_segments(num_words);
@@ -342,10 +395,47 @@ int hvlc_encode(hvlc_ctx* c,
     c->last_grid = (int)grid;
     const bool prof = c->ev && c->ev_used < c->ev_cap;
     if (prof) HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used], s));
-    HVLC_HIP(c, launch(k_encode, dim3((unsigned)grid), dim3(kEncThreads), sizeof(Smem), s, p));
+    {
+        void* ptrs[] = { (void*)&p };
+        hipError_t e = hipLaunchKernel(G::kernel(), dim3((unsigned)grid), dim3(G::threads), ptrs, G::smem, s);
+        if (e != hipSuccess) { c->last_hip = (int)e; return HVLC_ERR_HIP; }
+    }
     c->last_op = 1;                                           // (only a launched encode is what hvlc_finish reports on)
+    c->last_words = num_words;
     if (prof) { HVLC_HIP(c, hipEventRecord(c->ev[2 * c->ev_used + 1], s)); c->ev_used++; }
     return HVLC_OK;
+}
+
+extern "C" {
+
+int hvlc_encode(hvlc_ctx* c,
+                const uint32_t* d_in, uint64_t num_words,
+                const uint32_t* d_codewords, const uint32_t* d_codewordlens,
+                uint32_t* d_out_bits, uint64_t out_capacity_words,
+                uint64_t* d_out_offsets, uint64_t* d_total_bits,
+                void* stream)
+{
+    if (!c || !d_codewords || !d_codewordlens || !d_out_bits) return HVLC_ERR_ARG;
+    if (num_words && !d_in) return HVLC_ERR_ARG;
+    if (((uintptr_t)d_in & 15u) || ((uintptr_t)d_out_bits & 3u) || ((uintptr_t)d_out_offsets & 7u) ||
+        ((uintptr_t)d_total_bits & 7u))
+        return HVLC_ERR_ARG;
+    if (out_capacity_words < 1) return HVLC_ERR_ARG;
+    // The geometry of this call: ten data waves per workgroup and 40 KiB tiles, or -- when the context's last FINISHED
+    // encode produced more than ~3.4 bits per symbol (hvlc_finish) -- eight data waves with larger rings and 32 KiB
+    // tiles: at that density a 1752-word ring holds three parts, a 2188-word ring four (H4.0: +9 %; H2.2: -9 %).
+    int g = c->geometry_forced >= 0 ? c->geometry_forced : c->geometry;
+#ifndef HVLC_TWO_GEOMETRIES
+    g = 0;
+#endif
+    c->last_geometry = g;
+#ifdef HVLC_TWO_GEOMETRIES
+    if (g == 1)
+        return encode_with<Geo8>(c, c->blocks_per_cu8, d_in, num_words, d_codewords, d_codewordlens, d_out_bits, out_capacity_words,
+                                 d_out_offsets, d_total_bits, (hipStream_t)stream);
+#endif
+    return encode_with<Geo10>(c, c->blocks_per_cu, d_in, num_words, d_codewords, d_codewordlens, d_out_bits, out_capacity_words,
+                              d_out_offsets, d_total_bits, (hipStream_t)stream);
 }
 
 int hvlc_test_hook(hvlc_ctx* c, int which, int64_t value)
@@ -405,6 +495,12 @@ int hvlc_finish(hvlc_ctx* c, void* stream, uint64_t* total_bits)
     if (c->last_op == 1) {              // the last encode: the status word of the half it ran in (the call counter has moved on)
         flags = c->h_status[(c->h_status[kCtlCalls] + 1u) & 1u];
         memcpy(&bits, &c->h_status[2 * kCtlResult64], 8);
+        // the density of what this context encodes decides the geometry of its NEXT calls (hvlc_encode), with a margin
+        // against flapping: up at 3.4 bits per symbol, back at 3.2
+        if (flags == 0 && c->last_words >= (1u << 20)) {
+            const double bps = (double)bits / ((double)c->last_words * 4.0);
+            if (bps >= 3.4) c->geometry = 1; else if (bps <= 3.2) c->geometry = 0;
+        }
     } else if (c->last_op == 2) {
         flags = c->h_status[kCtlScanStatus];
         memcpy(&bits, &c->h_status[2 * kCtlScanResult64], 8);

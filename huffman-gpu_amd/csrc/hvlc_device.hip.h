@@ -45,12 +45,17 @@
 // bit, written once with ONE store and read by ONE lane with ONE load of the same width
 // (relaxed agent-scope, sc1) -- the form the CDNA4 guide lists as needing no release/acquire
 // fence -- and zero at the start of each launch (by the launch before it: EncodeParams).
-#pragma once
+// This header is included TWICE by hvlc_api.hip (no include guard): as namespace hvlc with ten data waves per encoder
+// workgroup, and as namespace hvlc8 with eight and larger rings (HVLC_NS, HVLC_DATA_WAVES, HVLC_WAVE_RING_WORDS) -- the
+// geometry for streams of more than ~3.4 bits per symbol, whose parts a 1752-word ring holds only three of.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace hvlc {
+#ifndef HVLC_NS
+#define HVLC_NS hvlc
+#endif
+namespace HVLC_NS {
 
 constexpr int      kThreads     = 256;                     // block size of the small kernels
 #ifndef HVLC_DATA_WAVES
@@ -2557,4 +2562,4 @@ __global__ void __launch_bounds__(kThreads) k_histogram(const uint8_t* data, uin
     if (s) atomicAdd(&hist[threadIdx.x], (unsigned long long)s);
 }
 
-}  // namespace hvlc
+}  // namespace HVLC_NS

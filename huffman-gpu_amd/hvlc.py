@@ -33,7 +33,7 @@ EXPORTS = [
     "hvlc_finish", "gpu_vlc_encode", "hvlc_segment_bits", "hvlc_exclusive_scan", "hvlc_rebase_offsets",
     "hvlc_rebase_offsets_dev", "hvlc_profile_begin", "hvlc_profile_collect",
     "hvlc_gen_symbols", "hvlc_histogram", "hvlc_build_table", "hvlc_merge_shard", "hvlc_decode", "hvlc_get_launch_info", "hvlc_last_hip_error",
-    "hvlc_status_string", "hvlc_version", "hvlc_test_hook", "hvlc_probe_bandwidth", "hvlc_get_clock_info",
+    "hvlc_status_string", "hvlc_version", "hvlc_test_hook", "hvlc_probe_bandwidth", "hvlc_get_clock_info", "hvlc_get_geometry",
 ]
 HOOK_STALL_TILE, HOOK_FORCE_GRID = 1, 2
 
@@ -124,6 +124,7 @@ def lib():
     L.hvlc_get_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.hvlc_last_hip_error.argtypes = [vp]
     L.hvlc_get_clock_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.hvlc_get_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.hvlc_test_hook.argtypes = [vp, i32, C.c_int64]
     L.hvlc_probe_bandwidth.argtypes = [vp, vp, u64, vp, u64, u32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.hvlc_status_string.argtypes = [i32]
@@ -211,7 +212,10 @@ class Encoder:
     def launch_info(self):
         g, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         lib().hvlc_get_launch_info(self._ctx, C.byref(g), C.byref(b), C.byref(c))
-        return {"grid_blocks": g.value, "blocks_per_cu": b.value, "compute_units": c.value}
+        last, nxt = C.c_int(0), C.c_int(0)
+        lib().hvlc_get_geometry(self._ctx, C.byref(last), C.byref(nxt))
+        return {"grid_blocks": g.value, "blocks_per_cu": b.value, "compute_units": c.value,
+                "data_waves": last.value, "data_waves_next": nxt.value}
 
     # ---- tensor API ----------------------------------------------------------------------
     def table_to_device(self, codewords, codewordlens):

@@ -223,6 +223,15 @@ int hvlc_decode(hvlc_ctx* ctx, const uint32_t* d_bits, uint64_t total_bits, cons
 enum { HVLC_HOOK_STALL_TILE = 1, HVLC_HOOK_FORCE_GRID = 2 };
 int hvlc_test_hook(hvlc_ctx* ctx, int which, int64_t value);
 
+/* The encoder has two workgroup geometries: ten data waves with 40 KiB tiles, and eight data waves with larger
+ * staging rings and 32 KiB tiles for dense output (more than ~3.4 bits per symbol: a ring of the first geometry holds
+ * only three parts then; the second is 9 % faster at 4 bits per symbol and 9 % slower at 2.2).  A context starts with
+ * the first and follows the density of its last FINISHED encode (hvlc_finish after an encode of at least 4 MiB: up at
+ * 3.4 bits per symbol, back at 3.2); a caller that never calls hvlc_finish stays with the first.  The output is the
+ * same bit for bit either way.  HVLC_GEOMETRY=10|8 in the environment of hvlc_create fixes it (tests).
+ * Returns the data waves per workgroup of the last encode launched and of the next one. */
+int hvlc_get_geometry(hvlc_ctx* ctx, int* data_waves_last, int* data_waves_next);
+
 /* Introspection: launch geometry chosen for this device (grid, blocks per CU,
  * CUs) and the last HIP error code seen by this context. */
 int hvlc_get_launch_info(hvlc_ctx* ctx, int* grid_blocks, int* blocks_per_cu, int* compute_units);

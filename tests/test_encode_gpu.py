@@ -128,6 +128,52 @@ def test_every_shape_of_the_last_tile(enc, kind):
         _check(enc, x, cw, cl, f"{kind}/{nwords}")
 
 
+def test_the_geometry_of_eight_data_waves_is_bit_exact(golden, monkeypatch):
+    """The encoder's second workgroup geometry (eight data waves, 32 KiB tiles, larger rings: what a context switches to for
+    dense output), fixed with HVLC_GEOMETRY=8: the golden file, ragged sizes, every shape of ITS last tile (a tile = 8192
+    words), adversarial tables."""
+    monkeypatch.setenv("HVLC_GEOMETRY", "8")
+    e = hvlc.Encoder(0, 1 << 22)
+    try:
+        x = np.tile(golden["period"], 4).view(np.uint32)
+        _check(e, x, golden["cw"], golden["cl"], "g1/8")
+        assert e.launch_info()["data_waves"] == 8
+        rng = np.random.default_rng(808)
+        for kind in ("short", "any", "len4", "all31", "zeros"):
+            cw, cl = random_table(rng, kind)
+            for nwords in (1, 257, 1024, 1025, 7168, 7169, 8191, 8192, 8193, 9216, 16384, 16385, 8192 * 64, 8192 * 65 - 1023, 12345, 65536 * 3 + 17):
+                xx = rng.integers(0, 1 << 32, nwords, dtype=np.uint64).astype(np.uint32)
+                _check(e, xx, cw, cl, f"8/{kind}/{nwords}")
+    finally:
+        e.close()
+
+
+def test_the_geometry_follows_the_density_of_the_last_finished_encode(monkeypatch):
+    """A context starts with ten data waves per workgroup; an encode of more than 3.4 bits per symbol that hvlc_finish has
+    reported on makes the NEXT calls use eight (larger rings: four parts of 4 bits per symbol instead of three), one
+    below 3.2 takes them back.  The stream is the oracle's either way."""
+    monkeypatch.delenv("HVLC_GEOMETRY", raising=False)
+    e = hvlc.Encoder(0, 1 << 22)
+    try:
+        rng = np.random.default_rng(909)
+        dense_cw, dense_cl = random_table(rng, "len4")                       # 4 bits per symbol
+        sparse_cl = np.full(256, 2, dtype=np.uint32); sparse_cw = (np.arange(256, dtype=np.uint32) & 3)   # 2 bits per symbol (not decodable; the encoder does not care)
+        x = rng.integers(0, 1 << 32, 1 << 21, dtype=np.uint64).astype(np.uint32)   # 8 MiB
+        assert e.launch_info()["data_waves_next"] == 10
+        _check(e, x, dense_cw, dense_cl, "dense/first")                     # (_check calls finish)
+        assert e.launch_info()["data_waves"] == 10 and e.launch_info()["data_waves_next"] == 8
+        _check(e, x, dense_cw, dense_cl, "dense/second")
+        assert e.launch_info()["data_waves"] == 8
+        _check(e, x[: 1 << 18], sparse_cw, sparse_cl, "sparse/small")       # below 4 MiB: no decision is taken from it
+        assert e.launch_info()["data_waves_next"] == 8
+        _check(e, x, sparse_cw, sparse_cl, "sparse")
+        assert e.launch_info()["data_waves"] == 8 and e.launch_info()["data_waves_next"] == 10
+        _check(e, x, sparse_cw, sparse_cl, "sparse/second")
+        assert e.launch_info()["data_waves"] == 10
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("kind", ["all31", "alt1_31", "zeros", "allzero", "len4", "len16", "len17"])
 def test_adversarial_tables(enc, kind):
     """All-31-bit codes (496 bits per 16 symbols: general path), alternating 1/31, mostly/all
