@@ -217,14 +217,19 @@ def main():
     # front and one behind (per-launch events cost 4-13 us per step: 1 % of a 4 GiB step, 12 % of a 256 MiB one,
     # tools/launch_gap.py)
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    import gc
+    gc.disable()                             # (no collector pause between the fences)
     fence()
     t0 = time.perf_counter()
     ev_a.record()
     for i in range(args.steps):
         step()
     ev_b.record()
+    while not ev_b.query():                  # the host spins until the last step is done: a blocking wait's wake-up costs
+        pass                                 # milliseconds on a busy host (one run of round 3: 2.7 ms on a 41 ms region)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     region_ms = ev_a.elapsed_time(ev_b)
     bits2, rc = enc.finish()
     assert rc == 0 and bits2 == bits
