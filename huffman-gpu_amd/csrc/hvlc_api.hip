@@ -174,8 +174,8 @@ int env_int(const char* name, int dflt)
 // find the ticket counters exhausted, so more than fits buys nothing.  The occupancy API is advisory: it can
 // over-report for SGPR-heavy kernels on ROCm 7.2 (CDNA4 guide), and it counts wave slots per CU, while a
 // workgroup whose wave count is not a multiple of 4 puts one wave more on one SIMD than on the others.  The
-// grid is therefore limited to what fits under the WORST placement; the 8-wave encoder workgroup (two waves
-// per SIMD) makes the placement irrelevant: three workgroups per CU at 80 VGPRs and 52 KiB of LDS each.
+// grid is therefore limited to what fits under the WORST placement; the 12-wave encoder workgroup (three waves
+// per SIMD; ten waves, two or three per SIMD, in the second geometry) fits twice per CU at 80 VGPRs and 73.5 KiB of LDS each.
 template <typename K>
 int pick_blocks_per_cu(hvlc_ctx* c, K kernel, int block_threads, size_t dyn_lds, int cap)
 {

@@ -54,7 +54,7 @@ typedef enum hvlc_status {
 typedef struct hvlc_ctx hvlc_ctx;   /* workspace: replaces preallocBlockSums/deallocBlockSums (scan.cu:67,98) */
 
 /* Create / destroy a context bound to `device`.  max_words sizes the workspace
- * (2 x 20 B per 28 KiB of input); it grows on demand if a later call is larger
+ * (2 x 20 B per 32 KiB of input); it grows on demand if a later call is larger
  * (a re-allocation: synchronises the device, and HIP graphs captured on this
  * context before it must not be replayed afterwards -- size it up front). */
 int hvlc_create(hvlc_ctx** ctx, int device, uint64_t max_words);
@@ -85,7 +85,7 @@ uint64_t hvlc_num_segments(uint64_t num_words);
  * memset) once the context is large enough: capturable into a HIP graph.
  * Errors found on the device (table, capacity, timeout) are reported by
  * hvlc_finish.  Not re-entrant per context (one encode in flight per ctx).
- * Device requirement: an input of more than one 40 KiB tile per resident
+ * Device requirement: an input of more than one tile (40 or 32 KiB) per resident
  * workgroup needs at least 64 workgroups resident at once (two per compute
  * unit: 32 CUs) -- fewer, e.g. a small compute partition, is HVLC_ERR_ARG.
  */
