@@ -516,7 +516,10 @@ constexpr int      kTixAhead = HVLC_TICKETS_AHEAD;         // tiles the scout dr
 constexpr int      kTixAheadMax = 3;
 static_assert(kTq >= kSlots + kTixAheadMax + 2, "a tile number must stay in the queue until the store wave has stored the tile");
 #ifndef HVLC_WAVE_RING_WORDS
-#define HVLC_WAVE_RING_WORDS 1752
+#define HVLC_WAVE_RING_WORDS 1784        // six slots of 296 words (H2.2's parts: 292-296) and a word of eight to spare
+#endif
+#ifndef HVLC_RING_SLOTS
+#define HVLC_RING_SLOTS 8                // a part takes a slot of the largest part's size so far, rounded up to this many words
 #endif
 constexpr uint32_t kWaveRing = HVLC_WAVE_RING_WORDS;       // staging ring of ONE data wave: 10 x 6.8 KiB per workgroup, two workgroups per CU
 constexpr uint32_t kNoRoom   = 0xffffffffu;
@@ -900,6 +903,9 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
     for (int r = 0; r < kRows; ++r) raw[r] = make_uint4(0, 0, 0, 0);
     uint32_t* const ring = sm.ring[wave];
     uint32_t n_loaded = 0, n_packed = 0, head = 0;           // workgroup-local tile indices: input loaded / part packed; ring: where the next part's words start
+#if HVLC_RING_SLOTS
+    uint32_t slot_words = 0;
+#endif
     uint32_t n_final = ~0u;
     const uint32_t last_tile = (uint32_t)(p.num_tiles - 1);
     // 32-bit word strings (encode16_w32): a part in which some word's four codewords exceed 32 bits is encoded again the
@@ -1053,7 +1059,14 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
                 // be packed (no ring words until older tiles are resolved) is published late, and every tile of its group
                 // waits for it.  Measured (tools/ab.py): 1 tile ahead is best at 3 parts per ring (4 bits per symbol: +6 %
                 // over 2), 3 at 9 parts (1.3 bits per symbol: +3 %), 2 in between.
+#ifdef HVLC_PARTS_GUARANTEED
+                // (allocations are contiguous: a part that does not fit before the ring's end starts over at word 0 and leaves
+                // up to need - 1 words unused -- what a ring holds FOR SURE is one part less than its size suggests)
+                const uint32_t need_avg = ring_need(Ttile / (uint32_t)kDataWaves);
+                const uint32_t parts = (kWaveRing + 1u) / need_avg > 1u ? (kWaveRing + 1u) / need_avg - 1u : 1u;
+#else
                 const uint32_t parts = kWaveRing / ring_need(Ttile / (uint32_t)kDataWaves);
+#endif
 #ifndef HVLC_AHEAD3_PARTS
 #define HVLC_AHEAD3_PARTS 8u
 #endif
@@ -1076,12 +1089,22 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
         } else if (!slow) {
             // ---- 4: ring words, pack, hand over
             uint32_t start;
-            if ((start = ring_place(sm, wave, head, n_packed, freed, need)) == kNoRoom) {
+#if HVLC_RING_SLOTS
+            // the words a part TAKES are a slot of the size the largest part so far needed (rounded up): parts of slightly
+            // different sizes otherwise leave a ring that holds "four" of them with room for three whenever the one that
+            // wraps round is a word or two larger than the one that left (3.25-3.75 bits per symbol: +20-28 %, tools/
+            // geometry_crossover.py)
+            if (need > slot_words || need + 64u < slot_words) slot_words = min((need + (uint32_t)(HVLC_RING_SLOTS) - 1u) & ~((uint32_t)(HVLC_RING_SLOTS) - 1u), kWaveRing);
+            const uint32_t take = slot_words;
+#else
+            const uint32_t take = need;
+#endif
+            if ((start = ring_place(sm, wave, head, n_packed, freed, take)) == kNoRoom) {
                 WaveWait w;
-                while ((start = ring_place(sm, wave, head, n_packed, lds_acq(&sm.n_freed), need)) == kNoRoom)
+                while ((start = ring_place(sm, wave, head, n_packed, lds_acq(&sm.n_freed), take)) == kNoRoom)
                     if (!w.step(p, sm, lane)) return;
             }
-            head = start + need;
+            head = start + take;
             if (lane == 0) *reinterpret_cast<uint2*>(&sm.wrec[slot][wave].start) = make_uint2(start, need);
             zero_words(ring + start, need / 4u, lane);       // (what an older part left there; the store wave only reads)
             uint32_t* const st = ring + start + 1;
