@@ -426,6 +426,38 @@ __device__ __forceinline__ void encode16_w32(const uint4& v, const uint2* lut, u
 // always three ORs, no per-lane branches, no left-alignment: with r = e % 32 and W = e / 32 the words W-2, W-1, W
 // take hi >> r, {hi,lo} >> r and lo << (32-r).  Words in front of the string (down to two words in front of st[0])
 // only ever receive an OR with zero.
+__device__ __forceinline__ void put_bits64_end(uint32_t* st, uint32_t e, uint64_t acc);
+__device__ __forceinline__ void put_row_pairs_mem(uint32_t* st, uint32_t q, const uint32_t* src, const uint2* lut, bool permuted);
+// A lane-row of more than 64 bits, re-read from memory (cold): as two HALVES of eight symbols when each fits 64 bits
+// (anything up to 8 bits per symbol on average: 4.5 bits per symbol ran at 0.9 TB/s through the pairs, tools/
+// geometry_crossover.py), else pair by pair.
+__device__ __forceinline__ void put_row_halves_mem(uint32_t* st, uint32_t q, const uint32_t* src, const uint2* lut, bool permuted)
+{
+    // (rolled loops, lengths first: cold code that must not cost the hot loop registers)
+    uint32_t l0 = 0, l1 = 0;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t w = hash4_if(src[k], permuted);
+        const uint32_t n = lut[w >> 24].y + lut[(w >> 16) & 255u].y + lut[(w >> 8) & 255u].y + lut[w & 255u].y;
+        if (k < 2) l0 += n; else l1 += n;
+    }
+    if (l0 > 64u || l1 > 64u) { put_row_pairs_mem(st, q, src, lut, permuted); return; }
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        uint64_t acc = 0;
+#pragma unroll 1
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t w = hash4_if(src[2 * h + k], permuted);
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                const uint2 e = lut[(w >> (8 * b)) & 255u];
+                acc = (acc << e.y) | e.x;                          // (lengths <= 31: the shift is defined)
+            }
+        }
+        q += h ? l1 : l0;
+        put_bits64_end(st, q, acc);
+    }
+}
 __device__ __forceinline__ void put_bits64_end(uint32_t* st, uint32_t e, uint64_t acc)
 {
     const uint32_t hi = (uint32_t)(acc >> 32), lo = (uint32_t)acc;
@@ -1123,7 +1155,7 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
                     for (int r = 0; r < kRows; ++r) {
                         if (tot[r] > 64u) {
                             const char* base = (const char*)p.in + (uint64_t)cur * (uint64_t)(kTileWords * 4);
-                            put_row_pairs_mem(st, rowbase[r] + incl[r] - tot[r],
+                            put_row_halves_mem(st, rowbase[r] + incl[r] - tot[r],
                                               (const uint32_t*)(base + (uint32_t)((wave * kRows + r) * 64 + cl) * 16u), sm.lut, permuted);
                         }
                     }
