@@ -550,6 +550,7 @@ static_assert(kTq >= kSlots + kTixAheadMax + 2, "a tile number must stay in the 
 #ifndef HVLC_WAVE_RING_WORDS
 #define HVLC_WAVE_RING_WORDS 1784        // six slots of 296 words (H2.2's parts: 292-296) and a word of eight to spare
 #endif
+constexpr int      kWideMax = 12;                          // lane-rows of more than 64 bits a wave keeps per part (the rest is re-read from memory)
 #ifndef HVLC_RING_SLOTS
 #define HVLC_RING_SLOTS 8                // a part takes a slot of the largest part's size so far, rounded up to this many words
 #endif
@@ -589,6 +590,8 @@ struct alignas(16) Smem {
     uint32_t  abort_flag;
     uint32_t  tix_ahead;                      // data -> scout: tiles to draw ahead of the slowest data wave (from the ring's capacity in parts)
     uint8_t   len_tmp[256];                   // prologue only: the table's lengths, for the layout decision (not zeroed)
+    uint4     wide[kDataWaves][kWideMax];     // the input words of lane-rows of more than 64 bits, kept from the encode to the pack
+                                              // phase (the registers take the next tile's input in between); not zeroed
 };
 static_assert(kDataWaves <= 16, "Smem::packed[] and the arrival counter hold up to 16 data waves");
 static_assert(2 * sizeof(Smem) <= 160 * 1024, "two workgroups per CU");
@@ -1047,6 +1050,19 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
             T         += (uint32_t)__builtin_amdgcn_readlane((int)incl[r], 63);
         }
 
+        // lane-rows of more than 64 bits (H2.2: one in 3000, i.e. in 55 % of the tiles) are packed from their input words in
+        // the pack phase: kept in LDS until then, a slot per row in lane order (the same count finds it again)
+        if (full && __any(max(max(tot[0], tot[1]), max(tot[2], tot[3])) > 64u)) {
+            const int cl = lane_id_fresh();
+            uint32_t nw = 0;
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                const uint64_t m = __ballot(tot[r] > 64u);
+                const uint32_t idx = nw + (uint32_t)__builtin_popcountll(m & ((1ull << cl) - 1ull));
+                if (tot[r] > 64u && idx < (uint32_t)kWideMax) sm.wide[wave][idx] = raw[r];
+                nw += (uint32_t)__builtin_popcountll(m);
+            }
+        }
         WS_LAP(kWsEncode);
         TLX(p, 5, wave == 0 && lane == 0 && n_packed == 0u);           // the first part is encoded and scanned
         // ---- 2: the next tile's loads.  (Issued EARLIER -- row by row between the lookups, each row into the registers its
@@ -1151,12 +1167,18 @@ __device__ __forceinline__ void encode_data_wave(const EncodeParams& p, Smem& sm
 #pragma unroll
                     for (int r = 0; r < kRows; ++r) put_bits64_end(st, rowbase[r] + incl[r], tot[r] <= 64u ? acc[r] : 0ull);
                     const int cl = lane_id_fresh();
+                    uint32_t nw = 0;
 #pragma unroll
                     for (int r = 0; r < kRows; ++r) {
+                        const uint64_t m = __ballot(tot[r] > 64u);
+                        const uint32_t idx = nw + (uint32_t)__builtin_popcountll(m & ((1ull << cl) - 1ull));
+                        nw += (uint32_t)__builtin_popcountll(m);
                         if (tot[r] > 64u) {
                             const char* base = (const char*)p.in + (uint64_t)cur * (uint64_t)(kTileWords * 4);
-                            put_row_halves_mem(st, rowbase[r] + incl[r] - tot[r],
-                                              (const uint32_t*)(base + (uint32_t)((wave * kRows + r) * 64 + cl) * 16u), sm.lut, permuted);
+                            const uint32_t* src = idx < (uint32_t)kWideMax
+                                                      ? reinterpret_cast<const uint32_t*>(&sm.wide[wave][idx])          // kept by the encode phase
+                                                      : (const uint32_t*)(base + (uint32_t)((wave * kRows + r) * 64 + cl) * 16u);
+                            put_row_halves_mem(st, rowbase[r] + incl[r] - tot[r], src, sm.lut, permuted);
                         }
                     }
                 }
